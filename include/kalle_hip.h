@@ -1,0 +1,209 @@
+/* kalle_hip.h - C-ABI of libkalle_hip.so: the MI355X (gfx950) kernels behind the kalle-audio DiT /
+ * audio-VAE hot path.
+ *
+ * The reference (18281818221/kalle-audio) has no FFI/operator interface for this path: its seam is
+ * Python nn.Module classes that call torch ops.  Each entry point below therefore
+ * names the reference call site (file:line under /root/reference) whose torch op it replaces; the
+ * Python drop-in modules in kalle_audio_amd/stable_audio_tools bind these with ctypes
+ * (INTEGRATION.md shows the binding a maintainer would add on the reference side).
+ *
+ * Conventions: plain device pointers + sizes, `stream` is a hipStream_t passed as void*, every call
+ * is asynchronous on that stream, allocates nothing, keeps no global state, and returns 0 on
+ * success or a negative KALLE_ERR_* code (never throws).  bf16 tensors are raw uint16 storage.
+ */
+#ifndef KALLE_HIP_H
+#define KALLE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KALLE_BF16 0
+#define KALLE_F32 1
+
+/* library / device info: returns the ABI version; fills the gfx arch name the code objects target */
+int kalle_abi_version(void);
+const char* kalle_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM (bf16 MFMA, fp32 accumulate) with fused epilogue.
+ *   C[M,N] = alpha * op(A) @ op(B)  (+bias[n]) (* sigmoid(1-gate[m/rows_per_batch, n])) (+residual[m,n]) (+C)
+ *   a_kmajor=0: A stored [M][K] (lda)   | a_kmajor=1: A stored [K][M] (lda)
+ *   b_kmajor=0: B stored [N][K] (ldb)   | b_kmajor=1: B stored [K][N] (ldb)
+ * forward  y = x @ W^T            : a_kmajor=0, b_kmajor=0  (nn.Linear: transformer.py:216,252,411,414,419,541,774,807)
+ * dgrad    dx = dy @ W            : a_kmajor=0, b_kmajor=1
+ * wgrad    dW = dy^T @ x          : a_kmajor=1, b_kmajor=1
+ * c_dtype: KALLE_BF16 or KALLE_F32.  N, K (and M when a_kmajor) must be multiples of 8; pointers 16-B aligned.
+ */
+typedef struct kalle_gemm_epilogue {
+    const float* bias;      /* [N] fp32 or NULL                                   (transformer.py:207,252 Linear bias) */
+    const float* gate;      /* [rows/rows_per_batch][ldg] fp32 or NULL: adaLN gate (transformer.py:667,681)            */
+    int64_t ldg;
+    int32_t rows_per_batch;
+    const float* residual;  /* [M][ldr] fp32 or NULL: residual stream add          (transformer.py:668,682,685-693)    */
+    int64_t ldr;
+    int32_t accumulate;     /* C += result (fp32 C only): gradient accumulation                                        */
+    float alpha;            /* 0 is read as 1                                                                          */
+    /* optional output-row remap (0 = off): logical row m is stored at row
+     *   (m / c_rows_per_batch) * c_batch_rows + c_row_offset + m % c_rows_per_batch   of C (and of residual):
+     * lets project_in write straight behind the prepended tokens of the residual stream (transformer.py:774-781) */
+    int32_t c_rows_per_batch;
+    int32_t c_batch_rows;
+    int32_t c_row_offset;
+} kalle_gemm_epilogue;
+
+int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+                    void* C, int64_t ldc, int c_dtype, int M, int N, int K,
+                    const kalle_gemm_epilogue* ep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (bias-less gamma, eps 1e-5) with optional adaLN modulation - one wavefront per row.
+ *   y = ((x-mean)*rstd*gamma + beta) * (1 + scale[b]) + shift[b]        (transformer.py:173-192, 660-665, 677-679)
+ * x: [rows][D] fp32 (residual stream) or bf16; y: bf16; mean/rstd: [rows] fp32 saved for backward.
+ * beta, scale, shift may be NULL.  D % 8 == 0, D <= 4096.
+ */
+int kalle_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                        const float* scale, const float* shift, int64_t ld_mod, int rows_per_batch,
+                        void* y, float* mean, float* rstd, int rows, int D, float eps, void* stream);
+
+/* backward of the above w.r.t. x and gamma/beta.
+ *   dx_out = dres + dLN/dx(dy)   (dres: incoming residual-stream gradient fp32 or NULL; may alias dx_out)
+ *   dgamma_part/dbeta_part: [nparts][D] fp32 partial sums (nparts = value returned by
+ *   kalle_layernorm_bwd_parts(rows)); reduce with kalle_colsum_f32.
+ */
+int kalle_layernorm_bwd_parts(int rows);
+int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* gamma,
+                        const float* scale, int64_t ld_mod, int rows_per_batch,
+                        const float* mean, const float* rstd, const float* dres, float* dx_out,
+                        float* dgamma_part, float* dbeta_part, int rows, int D, void* stream);
+
+/* adaLN modulation gradients: dscale[b,d] = sum_t dy*ln, dshift[b,d] = sum_t dy   (transformer.py:665,679) */
+int kalle_adaln_mod_bwd(const void* dy, const void* x, int x_dtype, const float* gamma, const float* beta,
+                        const float* mean, const float* rstd, float* dscale, float* dshift, int64_t ld_mod,
+                        int nbatch, int rows_per_batch, int D, void* stream);
+
+/* RMSNorm  y = x * scale * rsqrt(mean(x^2)+eps)   (blocks.py:268-272, 285-299; AdaRMSNorm 211-221 via scale=[b]) */
+int kalle_rmsnorm_fwd(const void* x, int x_dtype, const float* scale, int64_t ld_scale, int rows_per_batch,
+                      void* y, int y_dtype, float* rrms, int rows, int D, float eps, void* stream);
+int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale, int64_t ld_scale,
+                      int rows_per_batch, const float* rrms, float* dx, float* dscale_part, int rows, int D,
+                      void* stream);
+
+/* column sums: out[c] (+)= sum_r in[r][c]; in fp32 or bf16 [rows][ld]. Used for bias grads and partial reduces. */
+int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out, int rows, int cols, int accumulate,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / reductions on the DiT path
+ */
+/* SwiGLU: out[m, j] = h[m, j] * silu(h[m, inner + j])                     (transformer.py:218-219) */
+int kalle_swiglu_fwd(const void* h, void* out, int64_t rows, int inner, void* stream);
+/* dh[m, j] = dout*silu(g), dh[m, inner+j] = dout*x*silu'(g) */
+int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64_t rows, int inner, void* stream);
+/* SiLU on fp32/bf16 vectors (to_cond_embed / to_global_embed / to_scale_shift_gate: dit.py:39-72, transformer.py:641-644) */
+int kalle_silu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
+int kalle_silu_bwd(const void* dy, const void* x, void* dx, int dtype, int64_t n, void* stream);
+
+/* forward noising + target (training/diffusion.py:365-379, inference/sampling.py:8-11)
+ *   objective 0 ("v"): a=cos(pi t/2), s=sin(pi t/2); x_t = a x + s n ; target = a n - s x
+ *   objective 1 ("rectified_flow"): a=1-t, s=t ;     x_t = a x + s n ; target = n - x
+ * x, noise: fp32 [B][per_sample]; t fp32 [B]; x_t, target fp32.
+ */
+int kalle_diffuse_fwd(const float* x, const float* noise, const float* t, float* x_t, float* target,
+                      int nbatch, int64_t per_sample, int objective, void* stream);
+
+/* MSE loss (training/losses/losses.py:53-69): loss = mean((out-target)^2) over the masked elements,
+ * dout = dloss * 2 (out-target)/count.  mask: uint8 [B][T] over the last dim (broadcast over C) or NULL.
+ * out/target fp32 [B][C][T].  loss_sum[0] += sum of squares, loss_sum[1] += count (both must be zeroed by the caller);
+ * call kalle_mse_finish to produce loss and scale dout.
+ */
+int kalle_mse_fwd(const float* out, const float* target, const uint8_t* mask, float* loss_acc, float* diff,
+                  int nbatch, int C, int T, void* stream);
+int kalle_mse_finish(float* loss_acc, float* loss, float* diff, int64_t n, float weight, void* stream);
+
+/* batched 2-D transpose with dtype conversion (the "b c t -> b t c" rearranges of dit.py:199,219):
+ *   out[b][c][r] = in[b][r][c] for r < R, c < Cn; element (b,r,c) of `in` at b*in_batch_stride + r*in_ld + c,
+ *   element (b,c,r) of `out` at b*out_batch_stride + c*out_ld + r.  dtypes fp32 or bf16 independently. */
+int kalle_transpose_2d(const void* in, int in_dtype, int64_t in_batch_stride, int64_t in_ld, void* out,
+                       int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int R, int Cn,
+                       void* stream);
+
+/* strided row copy / cast / accumulate: out[b][r][0:cols] (+)= in[b][r][0:cols]  (cols, strides % 4 == 0).
+ * Used to splice the prepended conditioning token into the residual stream (transformer.py:776-787) and to
+ * gather token rows for GEMM operands. */
+int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_stride, int64_t in_ld, void* out,
+                    int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int rows, int cols,
+                    int accumulate, void* stream);
+
+/* dtype conversion fp32 <-> bf16 (n elements, n % 8 == 0 not required) */
+int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
+
+/* timestep Fourier features (blocks.py:84-93): out[b, j] = cos(2 pi t[b] w[j]), out[b, F/2+j] = sin(...) ; out bf16 or fp32 */
+int kalle_fourier_features(const float* t, const float* w, void* out, int out_dtype, int nbatch, int half,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention (non-causal, optional key mask), LDS-resident K/V tiles, bf16 MFMA, fp32 softmax.
+ *   out[b, i, h*64+d] = softmax_j(q_i . k_j / 8 + maskbias_j) v_j              (transformer.py:382-387, 494, 514-530)
+ * q/k/v are read in place from the projection outputs (no head transposes):
+ *   q: [B][Nq][ldq]  head h at column q_off + h*64 ; k: [B][Nk][ldk] at k_off + (h / (H/Hkv))*64 ; v likewise
+ *   (self-attention: q,k,v all point into the fused to_qkv output, ld = 3*D, offsets 0, D, 2D;
+ *    cross-attention: q from to_q (ld=D), k/v from to_kv output (ld=2*Dc, offsets 0, Dc); GQA repeat_interleave 337-340)
+ * rope_cos/rope_sin: [Npos][rot/2] fp32 tables or NULL - partial rotary on the first `rot` dims of q and k
+ *   (transformer.py:146-170, 430-444), applied on the fly.
+ * key_mask: uint8 [B][Nk] (1 = attend) or NULL.  lse: [B][H][Nq] fp32 saved for backward.  head dim fixed at 64.
+ */
+int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
+                        const void* v, int64_t ldv, int v_off, void* out, int64_t ldo, float* lse,
+                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                        int B, int H, int Hkv, int Nq, int Nk, void* stream);
+/* backward: dq/dk/dv written with the same strides/offsets into dq_buf/dk_buf/dv_buf (bf16). For GQA dk/dv are
+ * summed over the query heads sharing a kv head; RoPE is un-rotated on dq/dk. delta scratch: [B][H][Nq] fp32. */
+int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
+                        const void* v, int64_t ldv, int v_off, const void* out, const void* dout, int64_t ldo,
+                        const float* lse, float* delta, void* dq, void* dk, void* dv,
+                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                        int B, int H, int Hkv, int Nq, int Nk, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: fused Adam / AdamW over a flat fp32 master buffer, also emitting the bf16 compute copy.
+ *   (training/utils.py:88-93 torch.optim / FusedAdam; train_offline.py:94-100 AdamW)
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM, loss scaling, ...).
+ */
+int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                    int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1-D convolution stack of the audio VAEs (no MFMA; LDS line buffers, coalesced HBM).
+ * Layout (B, C, L) fp32 or bf16 activations, fp32 weights (weight-norm already folded: w = g * v/||v||).
+ */
+/* fold weight norm and repack to the kernels' weight layout [Cin][K][Cout] fp32 (once per forward; weights are frozen
+ * in every reference script, factory.py:77-80):
+ *   transposed=0 (Conv1d):          v [Cout=d0][Cin=d1][K], g [Cout] -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co,:,:]||
+ *   transposed=1 (ConvTranspose1d): v [Cin=d0][Cout=d1][K], g [Cin]  -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci,:,:]||
+ *   g == NULL: repack only (plain nn.Conv1d).   (dac.nn.layers.WNConv1d -> torch weight_norm; autoencoders.py:9) */
+int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
+                           int transposed, void* stream);
+/* y = conv1d(act(x), w, b, stride, padding, dilation) (+ residual) (-> tanh)
+ *   act: 0 none, 1 SnakeBeta (act_alpha/act_beta per input channel, exp() applied when act_logscale), 2 ELU
+ *   (autoencoders.py:39-62 ResidualUnit, 64-81 EncoderBlock, 116-191 encoder/decoder stems; blocks.py:301-339)
+ *   post: 0 none, 1 tanh (autoencoders.py:185).  ksize <= 16. */
+int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, const void* residual,
+                     void* y, int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
+                     int padding, int dilation, int act, const float* act_alpha, const float* act_beta,
+                     int act_logscale, int post, void* stream);
+/* y = conv_transpose1d(act(x), w, b, stride, padding), ksize <= 2*stride+1   (autoencoders.py:98-100 DecoderBlock) */
+int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
+                               int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
+                               int padding, int act, const float* act_alpha, const float* act_beta,
+                               int act_logscale, void* stream);
+/* standalone SnakeBeta: y = x + sin^2(x e^alpha) / (e^beta + 1e-9)     (blocks.py:301-339) */
+int kalle_snake_beta_fwd(const void* x, void* y, int dtype, const float* alpha, const float* beta, int logscale,
+                         int B, int C, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KALLE_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libkalle_hip.so.
+
+The prototypes are parsed from include/kalle_hip.h so the header stays the single source of truth for
+the C-ABI.  There is deliberately NO fallback: if the shared library is missing or a symbol cannot be
+resolved the import of the product path fails loudly (run `python -m kalle_audio_amd.build`).
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, "..", "include", "kalle_hip.h")
+LIB_PATH = os.path.join(HERE, "libkalle_hip.so")
+
+KALLE_BF16 = 0
+KALLE_F32 = 1
+
+
+class GemmEpilogue(ctypes.Structure):
+    """Mirror of `kalle_gemm_epilogue` (include/kalle_hip.h)."""
+    _fields_ = [
+        ("bias", ctypes.c_void_p),
+        ("gate", ctypes.c_void_p),
+        ("ldg", ctypes.c_int64),
+        ("rows_per_batch", ctypes.c_int32),
+        ("residual", ctypes.c_void_p),
+        ("ldr", ctypes.c_int64),
+        ("accumulate", ctypes.c_int32),
+        ("alpha", ctypes.c_float),
+        ("c_rows_per_batch", ctypes.c_int32),
+        ("c_batch_rows", ctypes.c_int32),
+        ("c_row_offset", ctypes.c_int32),
+    ]
+
+
+_CTYPE = {
+    "int": ctypes.c_int,
+    "int32_t": ctypes.c_int32,
+    "int64_t": ctypes.c_int64,
+    "float": ctypes.c_float,
+}
+
+
+def parse_header(path=HEADER):
+    """Return {name: (restype, [argtypes])} for every `kalle_*` function the header declares."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(kalle_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPE[a.split()[-2] if len(a.split()) > 1 else a])
+        protos[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, argtypes)
+    return protos
+
+
+class KalleError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "KALLE_ERR_ARG (bad shape/alignment/null pointer)", -2: "KALLE_ERR_LAUNCH (HIP launch failed)",
+        -3: "KALLE_ERR_UNSUPPORTED"}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KalleError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/torch fallback exists). "
+            "Build it with `python -m kalle_audio_amd.build`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in parse_header().items():
+        fn = getattr(lib, name)  # AttributeError -> loud failure on a missing symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise KalleError(f"{what} failed: {_ERR.get(code, code)}")

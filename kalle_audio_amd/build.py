@@ -1,0 +1,56 @@
+"""Build libkalle_hip.so (gfx950 code objects + C-ABI host stubs) in-tree with hipcc.
+
+`python -m kalle_audio_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libkalle_hip.so")
+SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "conv1d.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffast-math", "-fno-finite-math-only",
+         "-Wno-unused-value"]
+
+
+def _needs(obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(verbose=True, force=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "kalle_hip.h")]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _needs(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
+    if jobs or not os.path.exists(OUT):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,545 @@
+// Fused attention for the DiT block (gfx950), forward and backward, head dim 64, non-causal.
+// Reference: stable_audio_tools/models/transformer.py:396-547 (Attention.forward: rotary 430-444, key mask 446-462,
+// softmax(QK^T/sqrt(d))V 502-530 / SDPA 382-387, GQA repeat_interleave 337-340, 505-508) and
+// transformer.py:146-170 (rotate_half / apply_rotary_pos_emb, partial rotary on the first 32 dims).
+//
+// Design (sequences of ~126 latent frames at 12.5 Hz, S~130 context tokens): one workgroup of 4 waves owns a
+// 128-row block of one (batch, head); the whole 128-key K/V block is LDS-resident (one image per tensor,
+// [128][64] bf16 with a 160-B row stride that is conflict-free for BOTH ds_read_b128 row fragments and
+// ds_read_b64_tr_b16 transposed fragments), longer sequences loop over blocks with an online softmax.
+// Q/K/V are read in place from the projection outputs ([B][N][ld] with a column offset per head): no head
+// transposes ever touch HBM. RoPE is applied while staging Q/K into LDS (fp32 math, as the reference does) and
+// un-applied on dQ/dK in registers.
+// MFMA orientation: scores are computed TRANSPOSED (S^T = K Q^T) so that the softmax row statistics of a query
+// live in one lane (+2 shuffles) and the fp32 score accumulators are, after bf16 packing, directly the B operand
+// of the next MFMA (O^T = V^T P^T) - nothing but V^T (a hardware transposed LDS read) crosses lanes.
+#include "common.h"
+#include "../../include/kalle_hip.h"
+
+namespace {
+
+constexpr int AT_STRIDE = 160;             // bytes per LDS row: 64 bf16 + 32 B pad
+constexpr int AT_TILE = 128 * AT_STRIDE;   // 20480 B
+constexpr float SM_SCALE = 0.125f;         // 1/sqrt(64)
+constexpr float NEG_BIG = -1.0e30f;
+
+// stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying partial rotary (rot==32)
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
+                                           const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
+                                           int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 3, c = id & 7;
+        i32x4 v = {0, 0, 0, 0};
+        if (row < nvalid) {
+            const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
+            v = *reinterpret_cast<const i32x4*>(rp + 8 * c);
+            if (rot && c < 4) {
+                const i32x4 pv = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ 2));
+                const float* cp = cosT + (int64_t)(row0 + row) * 16 + (c & 1) * 8;
+                const float* sp = sinT + (int64_t)(row0 + row) * 16 + (c & 1) * 8;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const float sg = (c < 2) ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t0 = bf16lo((uint32_t)v[e]), t1 = bf16hi((uint32_t)v[e]);
+                    const float p0 = bf16lo((uint32_t)pv[e]), p1 = bf16hi((uint32_t)pv[e]);
+                    const float cc0 = e < 2 ? c0[2 * e] : c1[2 * e - 4], cc1 = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
+                    const float ss0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], ss1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+                    o[2 * e] = t0 * cc0 + sg * p0 * ss0;
+                    o[2 * e + 1] = t1 * cc1 + sg * p1 * ss1;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (int)pack_bf16x2(o[2 * e], o[2 * e + 1]);
+            }
+        }
+        *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * c) = v;
+    }
+}
+
+// fragment of 16 tile rows (rbase..) x 32 d (k-step s): MFMA operand whose k index is the head dim
+__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int rbase, int s, int lane) {
+    const int row = rbase + (lane & 15);
+    const int c = 4 * s + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds + row * AT_STRIDE + 16 * c);
+}
+// transposed fragment: MFMA operand whose k index is the TILE ROW and whose lane index is d (dbase + lane&15).
+// element j<4 -> row ra + 4g + j ; j>=4 -> row rb + 4g + (j-4): the k order of a packed accumulator pair.
+__device__ __forceinline__ bf16x8 trfrag(const char* lds, int ra, int rb, int dbase, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int qq = i >> 2, pp = i & 3;
+    const int cb = (dbase + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + (ra + 4 * g + qq) * AT_STRIDE + cb));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, lds + (rb + 4 * g + qq) * AT_STRIDE + cb));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    i32x4 w;
+    w[0] = (int)pack_bf16x2(a[0], a[1]);
+    w[1] = (int)pack_bf16x2(a[2], a[3]);
+    w[2] = (int)pack_bf16x2(b[0], b[1]);
+    w[3] = (int)pack_bf16x2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ float xor16_32_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor16_32_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttnParams {
+    const bf16_t* q; int64_t ldq; int q_off;
+    const bf16_t* k; int64_t ldk; int k_off;
+    const bf16_t* v; int64_t ldv; int v_off;
+    bf16_t* out; int64_t ldo;
+    float* lse;
+    const float* cosT; const float* sinT; int rot;
+    const uint8_t* mask;
+    int B, H, Hkv, Nq, Nk;
+    // backward only
+    const bf16_t* dout; const float* delta;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+};
+
+// ================================================================================================ forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = smem + AT_TILE;
+    char* Vs = smem + 2 * AT_TILE;
+    float* kbias = reinterpret_cast<float*>(smem + 3 * AT_TILE);  // [128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int hk = h / (p.H / p.Hkv);
+
+    const bf16_t* qsrc = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + h * 64;
+    const bf16_t* ksrc = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
+    const bf16_t* vsrc = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
+
+    stage_tile(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid);
+    __syncthreads();
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[qt][s] = rowfrag(Qs, wave * 32 + 16 * qt, s, lane);
+
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < p.Nk; k0 += 128) {
+        __syncthreads();  // previous block's K/V reads are done
+        const int kval = min(128, p.Nk - k0);
+        stage_tile(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
+        stage_tile(Vs, vsrc, p.ldv, k0, kval, nullptr, nullptr, 0, tid);
+        if (tid < 128) {
+            float bias = 0.f;
+            if (tid >= kval) bias = -INFINITY;                                           // padding: never attended
+            else if (p.mask && !p.mask[(int64_t)b * p.Nk + k0 + tid]) bias = NEG_BIG;      // masked_fill(-max)
+            kbias[tid] = bias;
+        }
+        __syncthreads();
+
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
+                acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][s], acc[kt][0], 0, 0, 0);
+                acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][s], acc[kt][1], 0, 0, 0);
+            }
+        }
+        // scale, mask, online softmax (query = lane&15 column; keys on rows 4g+reg of each key tile)
+        float mx[2] = {NEG_BIG, NEG_BIG};
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = acc[kt][qt][r] * SM_SCALE;
+                    sv = (kb[r] == 0.f) ? sv : kb[r];
+                    acc[kt][qt][r] = sv;
+                    mx[qt] = fmaxf(mx[qt], sv);
+                }
+        }
+        float alpha[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float mn = fmaxf(m[qt], xor16_32_max(mx[qt]));
+            alpha[qt] = __expf(m[qt] - mn);
+            m[qt] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __expf(acc[kt][qt][r] - mn);
+                    acc[kt][qt][r] = pv;
+                    ps += pv;
+                }
+            l[qt] = l[qt] * alpha[qt] + ps;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha[qt];
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 pb0 = pack_pair(acc[2 * ks][0], acc[2 * ks + 1][0]);
+            const bf16x8 pb1 = pack_pair(acc[2 * ks][1], acc[2 * ks + 1][1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vf = trfrag(Vs, 32 * ks, 32 * ks + 16, 16 * dt, lane);
+                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb0, o[dt][0], 0, 0, 0);
+                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb1, o[dt][1], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float lt = xor16_32_sum(l[qt]);
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const int qi = q0 + wave * 32 + 16 * qt + li;
+        if (qi < p.Nq) {
+            bf16_t* op = p.out + ((int64_t)b * p.Nq + qi) * p.ldo + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+                w[1] = (int)pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+                *reinterpret_cast<i32x2*>(op + 16 * dt) = w;
+            }
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + qi] = m[qt] + __logf(lt);
+        }
+    }
+}
+
+// ================================================================================================ backward
+// delta[b,h,q] = sum_d dout[b,q,h,d] * out[b,q,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                         int64_t ldo, float* __restrict__ delta, int B, int H, int Nq) {
+    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;  // (b, q, h)
+    const int sub = threadIdx.x & 7;
+    const int64_t total = (int64_t)B * Nq * H;
+    float s = 0.f;
+    int64_t bq = 0;
+    int h = 0;
+    if (item < total) {
+        bq = item / H;
+        h = (int)(item - bq * H);
+        const int64_t off = bq * ldo + h * 64 + sub * 8;
+        const i32x4 a = *reinterpret_cast<const i32x4*>(out + off);
+        const i32x4 d = *reinterpret_cast<const i32x4*>(dout + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            s += bf16lo((uint32_t)a[e]) * bf16lo((uint32_t)d[e]) + bf16hi((uint32_t)a[e]) * bf16hi((uint32_t)d[e]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (item < total && sub == 0) {
+        const int64_t b = bq / Nq, q = bq - b * Nq;
+        delta[(b * H + h) * Nq + q] = s;
+    }
+}
+
+// KV=true : owner = 128 keys of one kv head (grid: key blocks, Hkv, B); streams the queries of every head in the
+//           group; writes dK (un-rotated) and dV.   S[q,key] = Q K^T ; dV^T += dO^T P ; dK^T += Q^T dS
+// KV=false: owner = 128 queries of one head (grid: q blocks, H, B); streams the key blocks; writes dQ (un-rotated).
+//           S^T[key,q] = K Q^T ; dQ^T += K^T dS^T
+// In both, the owner's fragments sit in registers (B operand, "column" index on the lane) and the streamed tensors
+// are LDS images read as row fragments (A operand) and as transposed fragments.
+template <bool KV>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* R1 = smem;
+    char* R2 = smem + AT_TILE;
+    float* rowa = reinterpret_cast<float*>(smem + 2 * AT_TILE);  // [128] per streamed row: lse (KV) / key bias (!KV)
+    float* rowb = rowa + 128;                                    // [128] per streamed row: delta (KV)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z;
+    const int group = p.H / p.Hkv;
+    const int o0 = blockIdx.x * 128;  // owner block start
+    const int hown = blockIdx.y;      // kv head (KV) or q head (!KV)
+    const int hk = KV ? hown : hown / group;
+
+    const bf16_t* kbase = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
+    const bf16_t* vbase = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
+
+    // ---- owner fragments -> registers ----
+    if constexpr (KV) {
+        const int val = min(128, p.Nk - o0);
+        stage_tile(R1, kbase, p.ldk, o0, val, p.cosT, p.sinT, p.rot, tid);
+        stage_tile(R2, vbase, p.ldv, o0, val, nullptr, nullptr, 0, tid);
+    } else {
+        const int val = min(128, p.Nq - o0);
+        const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hown * 64;
+        const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hown * 64;
+        stage_tile(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid);
+        stage_tile(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
+    }
+    __syncthreads();
+    bf16x8 y1[2][2], y2[2][2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            y1[ot][s] = rowfrag(R1, wave * 32 + 16 * ot, s, lane);
+            y2[ot][s] = rowfrag(R2, wave * 32 + 16 * ot, s, lane);
+        }
+    // per-owner-column scalars
+    float ca[2], cb[2];  // KV: ca = key valid (1/0). !KV: ca = lse[q], cb = delta[q]
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        const int oi = o0 + wave * 32 + 16 * ot + li;
+        if constexpr (KV) {
+            bool ok = oi < p.Nk;
+            if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + oi] != 0;
+            ca[ot] = ok ? 1.f : 0.f;
+            cb[ot] = 0.f;
+        } else {
+            const bool ok = oi < p.Nq;
+            ca[ot] = ok ? p.lse[((int64_t)b * p.H + hown) * p.Nq + oi] : INFINITY;
+            cb[ot] = ok ? p.delta[((int64_t)b * p.H + hown) * p.Nq + oi] : 0.f;
+        }
+    }
+
+    f32x4 g1[4][2], g2[4][2];  // g2: dK^T / dQ^T accumulators [d tile][owner tile]; g1: dV^T (KV only)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            g1[dt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+            g2[dt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int nstream = KV ? p.Nq : p.Nk;
+    const int nheads = KV ? group : 1;
+    for (int hh = 0; hh < nheads; ++hh) {
+        const int hq = KV ? hk * group + hh : hown;
+        for (int s0 = 0; s0 < nstream; s0 += 128) {
+            __syncthreads();  // previous tile fully consumed (also guards the owner-fragment reads)
+            const int sval = min(128, nstream - s0);
+            if constexpr (KV) {
+                const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hq * 64;
+                const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hq * 64;
+                stage_tile(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                stage_tile(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
+                if (tid < 128) {
+                    const bool ok = tid < sval;
+                    const int64_t idx = ((int64_t)b * p.H + hq) * p.Nq + s0 + tid;
+                    rowa[tid] = ok ? p.lse[idx] : INFINITY;
+                    rowb[tid] = ok ? p.delta[idx] : 0.f;
+                }
+            } else {
+                stage_tile(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                stage_tile(R2, vbase, p.ldv, s0, sval, nullptr, nullptr, 0, tid);
+                if (tid < 128) {
+                    bool ok = tid < sval;
+                    if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + s0 + tid] != 0;
+                    rowa[tid] = ok ? 1.f : 0.f;
+                }
+            }
+            __syncthreads();
+
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                f32x4 sa[2][2], dp[2][2];  // [streamed tile of the pair][owner tile]
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int rb = 32 * pr + 16 * t;
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+                        sa[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        dp[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 x1 = rowfrag(R1, rb, s, lane);
+                        const bf16x8 x2 = rowfrag(R2, rb, s, lane);
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) {
+                            sa[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, y1[ot][s], sa[t][ot], 0, 0, 0);
+                            dp[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, y2[ot][s], dp[t][ot], 0, 0, 0);
+                        }
+                    }
+                    // P and dS in place (rows = streamed index 4g+r, column = owner index)
+                    const f32x4 ra = *reinterpret_cast<const f32x4*>(rowa + rb + 4 * g);
+                    f32x4 rbv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (KV) rbv = *reinterpret_cast<const f32x4*>(rowb + rb + 4 * g);
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pv, dl;
+                            if constexpr (KV) {
+                                pv = ca[ot] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ra[r]) : 0.f;
+                                dl = rbv[r];
+                            } else {
+                                pv = ra[r] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ca[ot]) : 0.f;
+                                dl = cb[ot];
+                            }
+                            sa[t][ot][r] = pv;
+                            dp[t][ot][r] = pv * (dp[t][ot][r] - dl) * SM_SCALE;
+                        }
+                }
+                bf16x8 pb[2], dsb[2];
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    pb[ot] = pack_pair(sa[0][ot], sa[1][ot]);
+                    dsb[ot] = pack_pair(dp[0][ot], dp[1][ot]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 a1 = trfrag(R1, 32 * pr, 32 * pr + 16, 16 * dt, lane);
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+                        g2[dt][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, dsb[ot], g2[dt][ot], 0, 0, 0);
+                    if constexpr (KV) {
+                        const bf16x8 a2 = trfrag(R2, 32 * pr, 32 * pr + 16, 16 * dt, lane);
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot)
+                            g1[dt][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, pb[ot], g1[dt][ot], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: un-rotate (transpose of the rotary map) and store; lane holds d = 16dt + 4g + r for its column
+    const int nown = KV ? p.Nk : p.Nq;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        const int oi = o0 + wave * 32 + 16 * ot + li;
+        if (oi >= nown) continue;
+        if (p.rot) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * 16 + 4 * g);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + (int64_t)oi * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = g2[0][ot][r], bb = g2[1][ot][r];
+                g2[0][ot][r] = a * c4[r] + bb * s4[r];
+                g2[1][ot][r] = bb * c4[r] - a * s4[r];
+            }
+        }
+        if constexpr (KV) {
+            bf16_t* dkp = p.dk + ((int64_t)b * p.Nk + oi) * p.ldk + p.k_off + hk * 64 + 4 * g;
+            bf16_t* dvp = p.dv + ((int64_t)b * p.Nk + oi) * p.ldv + p.v_off + hk * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(g2[dt][ot][0], g2[dt][ot][1]);
+                w[1] = (int)pack_bf16x2(g2[dt][ot][2], g2[dt][ot][3]);
+                *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
+                w[0] = (int)pack_bf16x2(g1[dt][ot][0], g1[dt][ot][1]);
+                w[1] = (int)pack_bf16x2(g1[dt][ot][2], g1[dt][ot][3]);
+                *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
+            }
+        } else {
+            bf16_t* dqp = p.dq + ((int64_t)b * p.Nq + oi) * p.ldq + p.q_off + hown * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(g2[dt][ot][0], g2[dt][ot][1]);
+                w[1] = (int)pack_bf16x2(g2[dt][ot][2], g2[dt][ot][3]);
+                *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
+            }
+        }
+    }
+}
+
+bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off, const void* v,
+                  int64_t ldv, int v_off, int64_t ldo, int rot, int B, int H, int Hkv, int Nq, int Nk) {
+    if (!q || !k || !v || B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) return false;
+    if (H % Hkv) return false;
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (q_off & 7) || (k_off & 7) || (v_off & 7)) return false;
+    if (rot != 0 && rot != 32) return false;
+    if (H > 65535 || B > 65535) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
+                                   const void* v, int64_t ldv, int v_off, void* out, int64_t ldo, float* lse,
+                                   const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                                   int B, int H, int Hkv, int Nq, int Nk, void* stream) {
+    if (!out || !check_common(q, ldq, q_off, k, ldk, k_off, v, ldv, v_off, ldo, rot, B, H, Hkv, Nq, Nk))
+        return KALLE_ERR_ARG;
+    if (rot && (!rope_cos || !rope_sin)) return KALLE_ERR_ARG;
+    AttnParams p{};
+    p.q = static_cast<const bf16_t*>(q); p.ldq = ldq; p.q_off = q_off;
+    p.k = static_cast<const bf16_t*>(k); p.ldk = ldk; p.k_off = k_off;
+    p.v = static_cast<const bf16_t*>(v); p.ldv = ldv; p.v_off = v_off;
+    p.out = static_cast<bf16_t*>(out); p.ldo = ldo; p.lse = lse;
+    p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk;
+    constexpr int lds = 3 * AT_TILE + 128 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    dim3 grid((Nq + 127) / 128, H, B), block(256);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, lds, static_cast<hipStream_t>(stream), p);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
+                                   const void* v, int64_t ldv, int v_off, const void* out, const void* dout,
+                                   int64_t ldo, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                   const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                                   int B, int H, int Hkv, int Nq, int Nk, void* stream) {
+    if (!out || !dout || !lse || !delta || !dq || !dk || !dv ||
+        !check_common(q, ldq, q_off, k, ldk, k_off, v, ldv, v_off, ldo, rot, B, H, Hkv, Nq, Nk))
+        return KALLE_ERR_ARG;
+    if (rot && (!rope_cos || !rope_sin)) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AttnParams p{};
+    p.q = static_cast<const bf16_t*>(q); p.ldq = ldq; p.q_off = q_off;
+    p.k = static_cast<const bf16_t*>(k); p.ldk = ldk; p.k_off = k_off;
+    p.v = static_cast<const bf16_t*>(v); p.ldv = ldv; p.v_off = v_off;
+    p.out = nullptr; p.ldo = ldo; p.lse = const_cast<float*>(lse);
+    p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk;
+    p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
+    p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
+
+    const int64_t items = (int64_t)B * Nq * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const bf16_t*>(out), p.dout, ldo, delta, B, H, Nq);
+    constexpr int lds = 2 * AT_TILE + 256 * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<true>), dim3((Nk + 127) / 128, Hkv, B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((attn_bwd_kernel<false>), dim3((Nq + 127) / 128, H, B), dim3(256), lds, st, p);
+    return kalle_check_launch();
+}

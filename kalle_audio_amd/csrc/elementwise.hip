@@ -1,0 +1,407 @@
+// HBM-bound elementwise / reduction kernels on the DiT train-step path (gfx950): vectorised 16-B
+// accesses, grid-stride loops capped at 2048 blocks, fp32 math on bf16 storage.
+// Reference call sites are cited per kernel.
+#include "common.h"
+#include "../../include/kalle_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t work_items, int block) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---- SwiGLU (transformer.py:218-219: x, gate = proj(x).chunk(2); x * silu(gate)) ---------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out,
+                                                         int64_t rows, int inner) {
+    const int cpr = inner >> 3;  // 8-element chunks per row
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * 8;
+        const i32x4 xv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + c);
+        const i32x4 gv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + inner + c);
+        i32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = bf16lo((uint32_t)xv[j]), x1 = bf16hi((uint32_t)xv[j]);
+            const float g0 = bf16lo((uint32_t)gv[j]), g1 = bf16hi((uint32_t)gv[j]);
+            o[j] = (int)pack_bf16x2(x0 * siluf_(g0), x1 * siluf_(g1));
+        }
+        *reinterpret_cast<i32x4*>(out + r * inner + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ h,
+                                                         bf16_t* __restrict__ dh, int64_t rows, int inner) {
+    const int cpr = inner >> 3;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * 8;
+        const i32x4 xv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + c);
+        const i32x4 gv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + inner + c);
+        const i32x4 dv = *reinterpret_cast<const i32x4*>(dout + r * inner + c);
+        i32x4 ox, og;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x[2] = {bf16lo((uint32_t)xv[j]), bf16hi((uint32_t)xv[j])};
+            float g[2] = {bf16lo((uint32_t)gv[j]), bf16hi((uint32_t)gv[j])};
+            float d[2] = {bf16lo((uint32_t)dv[j]), bf16hi((uint32_t)dv[j])};
+            float dx[2], dg[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float s = sigmoidf_(g[e]);
+                dx[e] = d[e] * g[e] * s;
+                dg[e] = d[e] * x[e] * s * (1.f + g[e] * (1.f - s));
+            }
+            ox[j] = (int)pack_bf16x2(dx[0], dx[1]);
+            og[j] = (int)pack_bf16x2(dg[0], dg[1]);
+        }
+        *reinterpret_cast<i32x4*>(dh + r * 2 * inner + c) = ox;
+        *reinterpret_cast<i32x4*>(dh + r * 2 * inner + inner + c) = og;
+    }
+}
+
+// ---- SiLU --------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void silu_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (F32) {
+            static_cast<float*>(y)[i] = siluf_(static_cast<const float*>(x)[i]);
+        } else {
+            static_cast<bf16_t*>(y)[i] = f32_to_bf16(siluf_(bf16_to_f32(static_cast<const bf16_t*>(x)[i])));
+        }
+    }
+}
+template <bool F32>
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                       void* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float xv, d;
+        if constexpr (F32) { xv = static_cast<const float*>(x)[i]; d = static_cast<const float*>(dy)[i]; }
+        else { xv = bf16_to_f32(static_cast<const bf16_t*>(x)[i]); d = bf16_to_f32(static_cast<const bf16_t*>(dy)[i]); }
+        const float s = sigmoidf_(xv);
+        const float r = d * s * (1.f + xv * (1.f - s));
+        if constexpr (F32) static_cast<float*>(dx)[i] = r; else static_cast<bf16_t*>(dx)[i] = f32_to_bf16(r);
+    }
+}
+
+// ---- forward noising + target (training/diffusion.py:365-379; sampling.py:8-11) --------------------
+__global__ __launch_bounds__(256) void diffuse_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                      const float* __restrict__ t, float* __restrict__ xt,
+                                                      float* __restrict__ target, int nbatch, int64_t per, int objective) {
+    const int64_t total = (int64_t)nbatch * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const float tv = t[b];
+        float a, s;
+        if (objective == 0) {
+            a = cosf(tv * 1.57079632679489662f);
+            s = sinf(tv * 1.57079632679489662f);
+        } else {
+            a = 1.f - tv;
+            s = tv;
+        }
+        const float xv = x[i], nv = noise[i];
+        xt[i] = xv * a + nv * s;
+        target[i] = objective == 0 ? (nv * a - xv * s) : (nv - xv);
+    }
+}
+
+// ---- MSE (training/losses/losses.py:53-69) -------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ out, const float* __restrict__ target,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ acc,
+                                                      float* __restrict__ diff, int nbatch, int C, int T) {
+    __shared__ float red[16];
+    const int64_t total = (int64_t)nbatch * C * T;
+    float s = 0.f, cnt = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float m = 1.f;
+        if (mask) {
+            const int64_t bc = i / T;
+            const int tt = (int)(i - bc * T);
+            const int b = (int)(bc / C);
+            m = mask[(int64_t)b * T + tt] ? 1.f : 0.f;
+        }
+        const float d = (out[i] - target[i]) * m;
+        if (diff) diff[i] = d;
+        s += d * d;
+        cnt += m;
+    }
+    s = block_sum(s, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) { atomicAdd(acc, s); atomicAdd(acc + 1, cnt); }
+}
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict__ acc, float* __restrict__ loss,
+                                                         float* __restrict__ diff, int64_t n, float weight) {
+    const float inv = 1.f / acc[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) *loss = weight * acc[0] * inv;
+    if (!diff) return;
+    const float k = 2.f * weight * inv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        diff[i] *= k;
+}
+
+// ---- batched 2-D transpose with dtype conversion -------------------------------------------------------
+template <bool IF32, bool OF32>
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, void* __restrict__ out, int R,
+                                                        int Cn, int64_t in_bs, int64_t out_bs, int64_t in_ld,
+                                                        int64_t out_ld) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < Cn) {
+            const int64_t idx = (int64_t)b * in_bs + (int64_t)r * in_ld + c;
+            if constexpr (IF32) v = static_cast<const float*>(in)[idx];
+            else v = bf16_to_f32(static_cast<const bf16_t*>(in)[idx]);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < Cn) {
+            const int64_t idx = (int64_t)b * out_bs + (int64_t)c * out_ld + r;
+            const float v = tile[tx][ty + 8 * i];
+            if constexpr (OF32) static_cast<float*>(out)[idx] = v;
+            else static_cast<bf16_t*>(out)[idx] = f32_to_bf16(v);
+        }
+    }
+}
+
+// ---- strided row copy with dtype conversion: out[b][r][:] = in[b][r][:]  -------------------------
+template <bool IF32, bool OF32>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                        int nbatch, int rows, int cols, int64_t in_bs, int64_t in_ld,
+                                                        int64_t out_bs, int64_t out_ld, int accumulate) {
+    const int cpr = cols >> 2;  // 4-element groups
+    const int64_t total = (int64_t)nbatch * rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t br = i / cpr;
+        const int c = (int)(i - br * cpr) * 4;
+        const int b = (int)(br / rows);
+        const int r = (int)(br - (int64_t)b * rows);
+        const int64_t ii = (int64_t)b * in_bs + (int64_t)r * in_ld + c;
+        const int64_t oi = (int64_t)b * out_bs + (int64_t)r * out_ld + c;
+        float v[4];
+        if constexpr (IF32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(static_cast<const float*>(in) + ii);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        } else {
+            const i32x2 a = *reinterpret_cast<const i32x2*>(static_cast<const bf16_t*>(in) + ii);
+            v[0] = bf16lo((uint32_t)a[0]); v[1] = bf16hi((uint32_t)a[0]);
+            v[2] = bf16lo((uint32_t)a[1]); v[3] = bf16hi((uint32_t)a[1]);
+        }
+        if constexpr (OF32) {
+            float* op = static_cast<float*>(out) + oi;
+            if (accumulate) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(op);
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            i32x2 o;
+            o[0] = (int)pack_bf16x2(v[0], v[1]);
+            o[1] = (int)pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<i32x2*>(static_cast<bf16_t*>(out) + oi) = o;
+        }
+    }
+}
+
+template <bool IF32, bool OF32>
+__global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if constexpr (IF32) v = static_cast<const float*>(in)[i];
+        else v = bf16_to_f32(static_cast<const bf16_t*>(in)[i]);
+        if constexpr (OF32) static_cast<float*>(out)[i] = v;
+        else static_cast<bf16_t*>(out)[i] = f32_to_bf16(v);
+    }
+}
+
+// ---- Fourier features (blocks.py:84-93) ---------------------------------------------------------------
+template <bool OF32>
+__global__ void fourier_kernel(const float* __restrict__ t, const float* __restrict__ w, void* __restrict__ out,
+                               int nbatch, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbatch * half) return;
+    const int b = i / half, j = i - b * half;
+    const float f = 6.283185307179586f * t[b] * w[j];
+    const float c = cosf(f), s = sinf(f);
+    if constexpr (OF32) {
+        static_cast<float*>(out)[(int64_t)b * 2 * half + j] = c;
+        static_cast<float*>(out)[(int64_t)b * 2 * half + half + j] = s;
+    } else {
+        static_cast<bf16_t*>(out)[(int64_t)b * 2 * half + j] = f32_to_bf16(c);
+        static_cast<bf16_t*>(out)[(int64_t)b * 2 * half + half + j] = f32_to_bf16(s);
+    }
+}
+
+// ---- fused Adam / AdamW ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ pb, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float wd, int decoupled, float bc1, float bc2,
+                                                   float gscale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gr = gv[e] * gscale;
+            if (decoupled) pv[e] *= (1.f - lr * wd); else gr += wd * pv[e];
+            mv[e] = b1 * mv[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2 + eps;   // torch.optim.Adam: sqrt(v)/sqrt(1-b2^t) + eps
+            pv[e] -= (lr / bc1) * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (pb) {
+            i32x2 o;
+            o[0] = (int)pack_bf16x2(pv[0], pv[1]);
+            o[1] = (int)pack_bf16x2(pv[2], pv[3]);
+            reinterpret_cast<i32x2*>(pb)[i] = o;
+        }
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float pv = p[i], gr = g[i] * gscale, mv = m[i], vv = v[i];
+        if (decoupled) pv *= (1.f - lr * wd); else gr += wd * pv;
+        mv = b1 * mv + (1.f - b1) * gr;
+        vv = b2 * vv + (1.f - b2) * gr * gr;
+        pv -= (lr / bc1) * (mv / (sqrtf(vv) / bc2 + eps));
+        p[i] = pv; m[i] = mv; v[i] = vv;
+        if (pb) pb[i] = f32_to_bf16(pv);
+    }
+}
+
+}  // namespace
+
+extern "C" int kalle_swiglu_fwd(const void* h, void* out, int64_t rows, int inner, void* stream) {
+    if (!h || !out || rows <= 0 || inner <= 0 || (inner & 7)) return KALLE_ERR_ARG;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(h), static_cast<bf16_t*>(out), rows,
+                       inner);
+    return kalle_check_launch();
+}
+extern "C" int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64_t rows, int inner, void* stream) {
+    if (!dout || !h || !dh || rows <= 0 || inner <= 0 || (inner & 7)) return KALLE_ERR_ARG;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(dout),
+                       static_cast<const bf16_t*>(h), static_cast<bf16_t*>(dh), rows, inner);
+    return kalle_check_launch();
+}
+extern "C" int kalle_silu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KALLE_F32) hipLaunchKernelGGL((silu_fwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
+    else hipLaunchKernelGGL((silu_fwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
+    return kalle_check_launch();
+}
+extern "C" int kalle_silu_bwd(const void* dy, const void* x, void* dx, int dtype, int64_t n, void* stream) {
+    if (!dy || !x || !dx || n <= 0) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KALLE_F32) hipLaunchKernelGGL((silu_bwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
+    else hipLaunchKernelGGL((silu_bwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
+    return kalle_check_launch();
+}
+extern "C" int kalle_diffuse_fwd(const float* x, const float* noise, const float* t, float* x_t, float* target,
+                                 int nbatch, int64_t per_sample, int objective, void* stream) {
+    if (!x || !noise || !t || !x_t || !target || nbatch <= 0 || per_sample <= 0 || (objective != 0 && objective != 1))
+        return KALLE_ERR_ARG;
+    hipLaunchKernelGGL(diffuse_kernel, dim3(grid_for((int64_t)nbatch * per_sample, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, noise, t, x_t, target, nbatch, per_sample, objective);
+    return kalle_check_launch();
+}
+extern "C" int kalle_mse_fwd(const float* out, const float* target, const uint8_t* mask, float* loss_acc, float* diff,
+                             int nbatch, int C, int T, void* stream) {
+    if (!out || !target || !loss_acc || nbatch <= 0 || C <= 0 || T <= 0) return KALLE_ERR_ARG;
+    int g = grid_for((int64_t)nbatch * C * T, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), out, target, mask,
+                       loss_acc, diff, nbatch, C, T);
+    return kalle_check_launch();
+}
+extern "C" int kalle_mse_finish(float* loss_acc, float* loss, float* diff, int64_t n, float weight, void* stream) {
+    if (!loss_acc || n < 0) return KALLE_ERR_ARG;
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(diff ? grid_for(n, 256) : 1), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), loss_acc, loss, diff, n, weight);
+    return kalle_check_launch();
+}
+extern "C" int kalle_transpose_2d(const void* in, int in_dtype, int64_t in_batch_stride, int64_t in_ld, void* out,
+                                  int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int R, int Cn,
+                                  void* stream) {
+    if (!in || !out || nbatch <= 0 || R <= 0 || Cn <= 0 || nbatch > 65535) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((Cn + 31) / 32, (R + 31) / 32, nbatch), block(256);
+    const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
+#define TL(I, O) hipLaunchKernelGGL((transpose_kernel<I, O>), grid, block, 0, st, in, out, R, Cn, in_batch_stride, \
+                                    out_batch_stride, in_ld, out_ld)
+    if (i32 && o32) TL(true, true); else if (i32) TL(true, false); else if (o32) TL(false, true); else TL(false, false);
+#undef TL
+    return kalle_check_launch();
+}
+extern "C" int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_stride, int64_t in_ld, void* out,
+                               int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int rows, int cols,
+                               int accumulate, void* stream) {
+    if (!in || !out || nbatch <= 0 || rows <= 0 || cols <= 0 || (cols & 3) || (in_ld & 3) || (out_ld & 3) ||
+        (in_batch_stride & 3) || (out_batch_stride & 3))
+        return KALLE_ERR_ARG;
+    if (accumulate && out_dtype != KALLE_F32) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for((int64_t)nbatch * rows * (cols >> 2), 256)), block(256);
+    const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
+#define CL(I, O) hipLaunchKernelGGL((copy_rows_kernel<I, O>), grid, block, 0, st, in, out, nbatch, rows, cols, \
+                                    in_batch_stride, in_ld, out_batch_stride, out_ld, accumulate)
+    if (i32 && o32) CL(true, true); else if (i32) CL(true, false); else if (o32) CL(false, true); else CL(false, false);
+#undef CL
+    return kalle_check_launch();
+}
+extern "C" int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream) {
+    if (!in || !out || n <= 0) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(grid_for(n, 256)), block(256);
+    const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
+#define CK(I, O) hipLaunchKernelGGL((cast_kernel<I, O>), grid, block, 0, st, in, out, n)
+    if (i32 && o32) CK(true, true); else if (i32) CK(true, false); else if (o32) CK(false, true); else CK(false, false);
+#undef CK
+    return kalle_check_launch();
+}
+extern "C" int kalle_fourier_features(const float* t, const float* w, void* out, int out_dtype, int nbatch, int half,
+                                      void* stream) {
+    if (!t || !w || !out || nbatch <= 0 || half <= 0) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((nbatch * half + 255) / 256), block(256);
+    if (out_dtype == KALLE_F32) hipLaunchKernelGGL((fourier_kernel<true>), grid, block, 0, st, t, w, out, nbatch, half);
+    else hipLaunchKernelGGL((fourier_kernel<false>), grid, block, 0, st, t, w, out, nbatch, half);
+    return kalle_check_launch();
+}
+extern "C" int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int decoupled, int step, float grad_scale, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return KALLE_ERR_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+                       grad, exp_avg, exp_avg_sq, static_cast<bf16_t*>(param_bf16), n, lr, beta1, beta2, eps,
+                       weight_decay, decoupled, bc1, bc2, grad_scale);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_abi_version(void) { return 1; }
+extern "C" const char* kalle_target_arch(void) { return "gfx950"; }

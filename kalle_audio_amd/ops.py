@@ -1,0 +1,295 @@
+"""Thin tensor-level wrappers over the C-ABI (kalle_audio_amd/_lib.py).
+
+Every function here takes CUDA (HIP) tensors, launches the hand-written gfx950 kernel on torch's current
+stream and returns immediately.  Nothing here falls back to torch math: CPU tensors raise.
+PyTorch is used only for device memory and streams.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import KALLE_BF16, KALLE_F32, GemmEpilogue, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return KALLE_BF16
+    if t.dtype == torch.float32:
+        return KALLE_F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("kalle_audio_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rows2d(t):
+    """(rows, ld) of a tensor viewed as a row-major matrix whose last dim is contiguous."""
+    assert t.stride(-1) == 1
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bfloat16, M=None, N=None, K=None,
+         lda=None, ldb=None, ldc=None, bias=None, gate=None, rows_per_batch=0, residual=None, accumulate=False,
+         alpha=1.0, c_rows_per_batch=0, c_batch_rows=0, c_row_offset=0):
+    """C = op(a) @ op(b) with the fused epilogue of kalle_gemm_bf16.
+
+    a: [M,K] (or [K,M] when a_kmajor), b: [N,K] (or [K,N] when b_kmajor); both bf16, last dim contiguous.
+    """
+    lib = _lib.load()
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    ar, ac = _rows2d(a)
+    br, bc = _rows2d(b)
+    if M is None:
+        M = ac if a_kmajor else ar
+    if K is None:
+        K = ar if a_kmajor else ac
+    if N is None:
+        N = bc if b_kmajor else br
+    lda = lda if lda is not None else a.stride(-2) if a.dim() >= 2 else ac
+    ldb = ldb if ldb is not None else b.stride(-2) if b.dim() >= 2 else bc
+    if out is None:
+        assert c_rows_per_batch == 0
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+    ldc = ldc if ldc is not None else out.stride(-2)
+    ep = GemmEpilogue()
+    ep.bias = bias.data_ptr() if bias is not None else None
+    ep.gate = gate.data_ptr() if gate is not None else None
+    ep.ldg = gate.stride(-2) if gate is not None else 0
+    ep.rows_per_batch = rows_per_batch
+    ep.residual = residual.data_ptr() if residual is not None else None
+    ep.ldr = residual.stride(-2) if residual is not None else 0
+    ep.accumulate = 1 if accumulate else 0
+    ep.alpha = alpha
+    ep.c_rows_per_batch, ep.c_batch_rows, ep.c_row_offset = c_rows_per_batch, c_batch_rows, c_row_offset
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if gate is not None:
+        assert gate.dtype == torch.float32
+    if residual is not None:
+        assert residual.dtype == torch.float32
+    check(lib.kalle_gemm_bf16(_p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc, _dt(out),
+                              M, N, K, ctypes.byref(ep), _stream()), "kalle_gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def layernorm_fwd(x, gamma, beta=None, scale=None, shift=None, rows_per_batch=0, eps=1e-5):
+    lib = _lib.load()
+    rows, D = _rows2d(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    ld_mod = scale.stride(-2) if scale is not None else (shift.stride(-2) if shift is not None else 0)
+    check(lib.kalle_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(scale), _p(shift), ld_mod, rows_per_batch,
+                                  _p(y), _p(mean), _p(rstd), rows, D, eps, _stream()), "kalle_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=None, dx_out=None, want_dbeta=False):
+    """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None)"""
+    lib = _lib.load()
+    rows, D = _rows2d(x)
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+    nparts = lib.kalle_layernorm_bwd_parts(rows)
+    dgp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
+    dbp = torch.empty((nparts, D), device=x.device, dtype=torch.float32) if want_dbeta else None
+    if dx_out is None:
+        dx_out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    ld_mod = scale.stride(-2) if scale is not None else 0
+    check(lib.kalle_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
+                                  _p(rstd), _p(dres), _p(dx_out), _p(dgp), _p(dbp), rows, D, _stream()),
+          "kalle_layernorm_bwd")
+    dgamma = colsum(dgp)
+    dbeta = colsum(dbp) if want_dbeta else None
+    return dx_out, dgamma, dbeta
+
+
+def adaln_mod_bwd(dy, x, gamma, beta, mean, rstd, nbatch, rows_per_batch):
+    lib = _lib.load()
+    D = x.shape[-1]
+    dscale = torch.empty((nbatch, D), device=x.device, dtype=torch.float32)
+    dshift = torch.empty((nbatch, D), device=x.device, dtype=torch.float32)
+    check(lib.kalle_adaln_mod_bwd(_p(dy), _p(x), _dt(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dscale),
+                                  _p(dshift), D, nbatch, rows_per_batch, D, _stream()), "kalle_adaln_mod_bwd")
+    return dscale, dshift
+
+
+def rmsnorm_fwd(x, scale, rows_per_batch=0, eps=1e-6, out_dtype=None):
+    lib = _lib.load()
+    rows, D = _rows2d(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    rrms = torch.empty(rows, device=x.device, dtype=torch.float32)
+    ld = scale.stride(-2) if scale.dim() >= 2 else 0
+    check(lib.kalle_rmsnorm_fwd(_p(x), _dt(x), _p(scale), ld, rows_per_batch, _p(y), _dt(y), _p(rrms), rows, D, eps,
+                                _stream()), "kalle_rmsnorm_fwd")
+    return y, rrms
+
+
+def rmsnorm_bwd(dy, x, scale, rrms, rows_per_batch=0):
+    lib = _lib.load()
+    rows, D = _rows2d(x)
+    dy = dy.contiguous()
+    nparts = lib.kalle_layernorm_bwd_parts(rows)
+    dsp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
+    dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    ld = scale.stride(-2) if scale.dim() >= 2 else 0
+    check(lib.kalle_rmsnorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(scale), ld, rows_per_batch, _p(rrms), _p(dx),
+                                _p(dsp), rows, D, _stream()), "kalle_rmsnorm_bwd")
+    return dx, colsum(dsp)
+
+
+def colsum(x, out=None, accumulate=False):
+    lib = _lib.load()
+    rows, cols = _rows2d(x)
+    ld = x.stride(-2) if x.dim() >= 2 else cols
+    if out is None:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(lib.kalle_colsum(_p(x), _dt(x), ld, _p(out), rows, cols, int(accumulate), _stream()), "kalle_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def swiglu_fwd(h):
+    lib = _lib.load()
+    rows, two_inner = _rows2d(h)
+    inner = two_inner // 2
+    out = torch.empty(h.shape[:-1] + (inner,), device=h.device, dtype=torch.bfloat16)
+    check(lib.kalle_swiglu_fwd(_p(h), _p(out), rows, inner, _stream()), "kalle_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(dout, h):
+    lib = _lib.load()
+    rows, two_inner = _rows2d(h)
+    dh = torch.empty_like(h)
+    check(lib.kalle_swiglu_bwd(_p(dout), _p(h), _p(dh), rows, two_inner // 2, _stream()), "kalle_swiglu_bwd")
+    return dh
+
+
+def silu_fwd(x):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.kalle_silu_fwd(_p(x), _p(y), _dt(x), x.numel(), _stream()), "kalle_silu_fwd")
+    return y
+
+
+def silu_bwd(dy, x):
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    check(lib.kalle_silu_bwd(_p(dy), _p(x), _p(dx), _dt(x), x.numel(), _stream()), "kalle_silu_bwd")
+    return dx
+
+
+def diffuse_fwd(x, noise, t, objective="v"):
+    lib = _lib.load()
+    x = x.contiguous()
+    noise = noise.contiguous()
+    xt = torch.empty_like(x)
+    target = torch.empty_like(x)
+    B = x.shape[0]
+    check(lib.kalle_diffuse_fwd(_p(x), _p(noise), _p(t), _p(xt), _p(target), B, x.numel() // B,
+                                0 if objective == "v" else 1, _stream()), "kalle_diffuse_fwd")
+    return xt, target
+
+
+def mse_loss(out, target, mask=None, weight=1.0, want_grad=True):
+    """returns (loss scalar tensor, dout or None). out/target fp32 [B,C,T]; mask bool/uint8 [B,T]."""
+    lib = _lib.load()
+    out = out.contiguous()
+    target = target.contiguous()
+    B, C, T = out.shape
+    acc = torch.zeros(2, device=out.device, dtype=torch.float32)
+    diff = torch.empty_like(out) if want_grad else None
+    m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+    check(lib.kalle_mse_fwd(_p(out), _p(target), _p(m8), _p(acc), _p(diff), B, C, T, _stream()), "kalle_mse_fwd")
+    loss = torch.empty((), device=out.device, dtype=torch.float32)
+    check(lib.kalle_mse_finish(_p(acc), _p(loss), _p(diff), out.numel(), weight, _stream()), "kalle_mse_finish")
+    return loss, diff
+
+
+def transpose_2d(x, out_dtype=None, out=None, R=None, Cn=None, in_batch_stride=None, in_ld=None,
+                 out_batch_stride=None, out_ld=None):
+    """out[b][c][r] = x[b][r][c]"""
+    lib = _lib.load()
+    B = x.shape[0]
+    R = R if R is not None else x.shape[1]
+    Cn = Cn if Cn is not None else x.shape[2]
+    in_batch_stride = in_batch_stride if in_batch_stride is not None else x.stride(0)
+    in_ld = in_ld if in_ld is not None else x.stride(1)
+    if out is None:
+        out = torch.empty((B, Cn, R), device=x.device, dtype=out_dtype or x.dtype)
+    out_batch_stride = out_batch_stride if out_batch_stride is not None else out.stride(0)
+    out_ld = out_ld if out_ld is not None else out.stride(1)
+    check(lib.kalle_transpose_2d(_p(x), _dt(x), in_batch_stride, in_ld, _p(out), _dt(out), out_batch_stride, out_ld,
+                                 B, R, Cn, _stream()), "kalle_transpose_2d")
+    return out
+
+
+def copy_rows(src, dst, nbatch, rows, cols, src_batch_stride, src_ld, dst_batch_stride, dst_ld, accumulate=False):
+    lib = _lib.load()
+    check(lib.kalle_copy_rows(_p(src), _dt(src), src_batch_stride, src_ld, _p(dst), _dt(dst), dst_batch_stride,
+                              dst_ld, nbatch, rows, cols, int(accumulate), _stream()), "kalle_copy_rows")
+    return dst
+
+
+def cast(x, dtype):
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(lib.kalle_cast(_p(x), _dt(x), _p(out), _dt(out), x.numel(), _stream()), "kalle_cast")
+    return out
+
+
+def fourier_features(t, w, out_dtype=torch.float32):
+    lib = _lib.load()
+    B, half = t.shape[0], w.shape[0]
+    out = torch.empty((B, 2 * half), device=t.device, dtype=out_dtype)
+    check(lib.kalle_fourier_features(_p(t.contiguous()), _p(w.contiguous()), _p(out), _dt(out), B, half, _stream()),
+          "kalle_fourier_features")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, param_bf16, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              decoupled=False, step=1, grad_scale=1.0):
+    lib = _lib.load()
+    check(lib.kalle_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param_bf16), param.numel(), lr,
+                              beta1, beta2, eps, weight_decay, int(decoupled), step, grad_scale, _stream()),
+          "kalle_adam_step")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention_fwd(q, k, v, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq, Nk, rope=None, key_mask=None):
+    """q/k/v: base tensors (bf16) of the projection outputs; see kalle_attention_fwd. Returns (out [B,Nq,H*64], lse)."""
+    lib = _lib.load()
+    out = torch.empty((B, Nq, H * 64), device=q.device, dtype=torch.bfloat16)
+    lse = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    cos, sin, rot = (rope[0], rope[1], rope[0].shape[-1] * 2) if rope is not None else (None, None, 0)
+    m8 = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
+    check(lib.kalle_attention_fwd(_p(q), ldq, q_off, _p(k), ldk, k_off, _p(v), ldv, v_off, _p(out), H * 64, _p(lse),
+                                  _p(cos), _p(sin), rot, _p(m8), B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq, Nk,
+                  rope=None, key_mask=None):
+    lib = _lib.load()
+    delta = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    cos, sin, rot = (rope[0], rope[1], rope[0].shape[-1] * 2) if rope is not None else (None, None, 0)
+    m8 = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
+    check(lib.kalle_attention_bwd(_p(q), ldq, q_off, _p(k), ldk, k_off, _p(v), ldv, v_off, _p(out), _p(dout), H * 64,
+                                  _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(cos), _p(sin), rot, _p(m8),
+                                  B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_bwd")

@@ -1,0 +1,376 @@
+"""-m gpu: every HIP kernel called through the C-ABI, checked against plain torch fp32 math of the same op
+(torch is only the checker here; the product path never calls these torch ops)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.float()
+    b = b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from kalle_audio_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _mk(shape, dev, ints=False, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if ints:
+        return torch.randint(-3, 4, shape, generator=g).float().to(dev)
+    return torch.randn(shape, generator=g).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 136, 72), (1008, 384, 192), (77, 24, 16), (256, 512, 1536)])
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_layouts_exact_int(ops, dev, M, N, K, akm, bkm):
+    """small-integer operands: products/sums are exact in bf16 x bf16 -> fp32, so any layout / lane-map error shows
+    as an exact mismatch (asymmetric random B: a transposed C write cannot hide)."""
+    if akm and M % 8:
+        M = (M + 7) // 8 * 8
+    A = _mk((M, K), dev, ints=True, seed=1)
+    Bm = _mk((N, K), dev, ints=True, seed=2)
+    ref = A @ Bm.t()
+    a = (A.t().contiguous() if akm else A).bfloat16()
+    b = (Bm.t().contiguous() if bkm else Bm).bfloat16()
+    out = ops.gemm(a, b, a_kmajor=bool(akm), b_kmajor=bool(bkm), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
+    assert torch.equal(out, ref), f"max diff {(out - ref).abs().max().item()}"
+
+
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_random_bf16_out(ops, dev, akm, bkm):
+    M, N, K = 520, 264, 328
+    A = _mk((M, K), dev, seed=3).bfloat16()
+    Bm = _mk((N, K), dev, seed=4).bfloat16()
+    ref = A.float() @ Bm.float().t()
+    a = A.t().contiguous() if akm else A
+    b = Bm.t().contiguous() if bkm else Bm
+    out = ops.gemm(a, b, a_kmajor=bool(akm), b_kmajor=bool(bkm))
+    assert out.dtype == torch.bfloat16
+    assert rel_l2(out, ref) < 4e-3  # bf16 output rounding only
+
+
+def test_gemm_epilogue(ops, dev):
+    Bt, T, N, K = 3, 40, 136, 72
+    M = Bt * T
+    A = _mk((M, K), dev, seed=5).bfloat16()
+    W = _mk((N, K), dev, seed=6).bfloat16()
+    bias = _mk((N,), dev, seed=7)
+    gate = _mk((Bt, N), dev, seed=8)
+    res = _mk((M, N), dev, seed=9)
+    base = A.float() @ W.float().t()
+    ref = (base + bias) * torch.sigmoid(1 - gate).repeat_interleave(T, 0) + res
+    out = ops.gemm(A, W, out_dtype=torch.float32, bias=bias, gate=gate, rows_per_batch=T, residual=res)
+    assert rel_l2(out, ref) < 1e-5
+    # accumulate + alpha
+    c = res.clone()
+    ops.gemm(A, W, out=c, accumulate=True, alpha=0.5)
+    assert rel_l2(c, res + 0.5 * base) < 1e-5
+    # row remap: write behind one prepended row per batch
+    stream = torch.zeros((Bt, T + 1, N), device=dev)
+    ops.gemm(A, W, out=stream.view(Bt * (T + 1), N), c_rows_per_batch=T, c_batch_rows=T + 1, c_row_offset=1)
+    assert rel_l2(stream[:, 1:], base.view(Bt, T, N)) < 1e-5
+    assert stream[:, 0].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("D", [128, 1536, 2048])
+@pytest.mark.parametrize("ada", [False, True])
+def test_layernorm_fwd_bwd(ops, dev, D, ada):
+    Bt, T = 3, 21
+    rows = Bt * T
+    x = _mk((rows, D), dev, seed=10) * 2 + 0.3
+    gamma = 1 + 0.1 * _mk((D,), dev, seed=11)
+    scale = 0.2 * _mk((Bt, D), dev, seed=12) if ada else None
+    shift = 0.2 * _mk((Bt, D), dev, seed=13) if ada else None
+    dy = _mk((rows, D), dev, seed=14).bfloat16()
+    dres = _mk((rows, D), dev, seed=15)
+
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    sr = scale.clone().requires_grad_(True) if ada else None
+    hr = shift.clone().requires_grad_(True) if ada else None
+    ln = F.layer_norm(xr, (D,), gr, None)
+    yr = ln
+    if ada:
+        yr = ln * (1 + sr.repeat_interleave(T, 0)) + hr.repeat_interleave(T, 0)
+    yr.backward(dy.float())
+
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, None, scale, shift, rows_per_batch=T)
+    assert rel_l2(y, yr) < 4e-3
+    dx, dgamma, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, scale=scale, rows_per_batch=T, dres=dres)
+    assert rel_l2(dx, xr.grad + dres) < 1e-4
+    assert rel_l2(dgamma, gr.grad) < 1e-4
+    if ada:
+        dsc, dsh = ops.adaln_mod_bwd(dy, x, gamma, None, mean, rstd, Bt, T)
+        assert rel_l2(dsc, sr.grad) < 1e-4
+        assert rel_l2(dsh, hr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("D", [64, 2048])
+def test_rmsnorm(ops, dev, D):
+    rows = 50
+    x = (_mk((rows, D), dev, seed=16)).bfloat16()
+    scale = 1 + 0.1 * _mk((D,), dev, seed=17)
+    dy = _mk((rows, D), dev, seed=18).bfloat16()
+    xr = x.float().requires_grad_(True)
+    sr = scale.clone().requires_grad_(True)
+    yr = xr * (sr * torch.rsqrt((xr ** 2).mean(-1, keepdim=True) + 1e-6))
+    yr.backward(dy.float())
+    y, rr = ops.rmsnorm_fwd(x, scale, eps=1e-6)
+    assert rel_l2(y, yr) < 4e-3
+    dx, dscale = ops.rmsnorm_bwd(dy, x, scale, rr)
+    assert rel_l2(dx, xr.grad) < 1e-4
+    assert rel_l2(dscale, sr.grad) < 1e-4
+
+
+def test_colsum(ops, dev):
+    x = _mk((777, 130), dev, seed=19)
+    assert rel_l2(ops.colsum(x), x.sum(0)) < 1e-5
+    xb = x.bfloat16()
+    assert rel_l2(ops.colsum(xb), xb.float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_swiglu_silu(ops, dev):
+    h = _mk((37, 256), dev, seed=20).bfloat16()
+    dout = _mk((37, 128), dev, seed=21).bfloat16()
+    hr = h.float().requires_grad_(True)
+    xx, gg = hr.chunk(2, -1)
+    o = xx * F.silu(gg)
+    o.backward(dout.float())
+    assert rel_l2(ops.swiglu_fwd(h), o) < 4e-3
+    assert rel_l2(ops.swiglu_bwd(dout, h), hr.grad) < 5e-3
+    x = _mk((1000,), dev, seed=22)
+    xr = x.clone().requires_grad_(True)
+    F.silu(xr).backward(torch.ones_like(x) * 0.5)
+    assert rel_l2(ops.silu_fwd(x), F.silu(x)) < 1e-6
+    assert rel_l2(ops.silu_bwd(torch.full_like(x, 0.5), x), xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("objective", ["v", "rectified_flow"])
+def test_diffuse_and_mse(ops, dev, objective):
+    B, C, T = 4, 16, 125
+    x = _mk((B, C, T), dev, seed=23)
+    n = _mk((B, C, T), dev, seed=24)
+    t = torch.rand(B, device=dev)
+    if objective == "v":
+        a, s = torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
+    else:
+        a, s = 1 - t, t
+    a, s = a[:, None, None], s[:, None, None]
+    xt, tgt = ops.diffuse_fwd(x, n, t, objective)
+    assert rel_l2(xt, x * a + n * s) < 1e-6
+    assert rel_l2(tgt, (n * a - x * s) if objective == "v" else (n - x)) < 1e-6
+    out = _mk((B, C, T), dev, seed=25)
+    mask = torch.rand(B, T, device=dev) > 0.3
+    for m in (None, mask):
+        o = out.clone().requires_grad_(True)
+        l = F.mse_loss(o, tgt, reduction="none")
+        if m is not None:
+            l = l[m.unsqueeze(1).repeat(1, C, 1)]
+        l = l.mean()
+        l.backward()
+        loss, dout = ops.mse_loss(out, tgt, m)
+        assert abs(loss.item() - l.item()) < 1e-5 * max(1, abs(l.item()))
+        assert rel_l2(dout, o.grad) < 1e-5
+
+
+def test_transpose_copy_cast_fourier(ops, dev):
+    x = _mk((3, 50, 40), dev, seed=26)
+    assert torch.equal(ops.transpose_2d(x), x.transpose(1, 2).contiguous())
+    assert rel_l2(ops.transpose_2d(x, out_dtype=torch.bfloat16), x.transpose(1, 2)) < 4e-3
+    # drop first row of each batch while transposing: in rows 1.., R=49
+    o = ops.transpose_2d(x[:, 1:], R=49, Cn=40, in_batch_stride=x.stride(0), in_ld=x.stride(1))
+    assert torch.equal(o, x[:, 1:].transpose(1, 2).contiguous())
+    dst = torch.zeros((3, 51, 40), device=dev)
+    ops.copy_rows(x, dst[:, 1:], 3, 50, 40, x.stride(0), x.stride(1), dst.stride(0), dst.stride(1))
+    assert torch.equal(dst[:, 1:], x) and dst[:, 0].abs().max().item() == 0
+    assert torch.equal(ops.cast(x, torch.bfloat16), x.bfloat16())
+    t = torch.rand(5, device=dev)
+    w = _mk((128,), dev, seed=27)
+    f = 2 * math.pi * t[:, None] * w[None, :]
+    assert rel_l2(ops.fourier_features(t, w), torch.cat([f.cos(), f.sin()], -1)) < 1e-4
+
+
+@pytest.mark.parametrize("decoupled", [False, True])
+def test_adam(ops, dev, decoupled):
+    n = 1003
+    p = _mk((n,), dev, seed=28)
+    ref = torch.nn.Parameter(p.clone())
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref], lr=1e-2, weight_decay=0.1)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    pb = torch.empty(n, device=dev, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = _mk((n,), dev, seed=30 + step)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, pb, lr=1e-2, weight_decay=0.1, decoupled=decoupled, step=step)
+    assert rel_l2(p, ref.data) < 1e-5
+    assert torch.equal(pb, p.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _rope_tables(n, dev):
+    inv = 1.0 / (10000 ** (torch.arange(0, 32, 2, device=dev).float() / 32))
+    f = torch.arange(n, device=dev).float()[:, None] * inv[None, :]
+    return f.cos().contiguous(), f.sin().contiguous()
+
+
+def _rope_ref(t, cos, sin):
+    # t [B,H,N,64]; rotary on first 32 dims (transformer.py:146-170)
+    c = torch.cat([cos, cos], -1)[None, None]
+    s = torch.cat([sin, sin], -1)[None, None]
+    r, u = t[..., :32], t[..., 32:]
+    x1, x2 = r[..., :16], r[..., 16:]
+    rh = torch.cat([-x2, x1], -1)
+    return torch.cat([r * c + rh * s, u], -1)
+
+
+def _attn_ref(q, k, v, mask, rope, H, Hkv):
+    # q [B,Nq,H*64], k/v [B,Nk,Hkv*64] fp32
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    qh = q.view(B, Nq, H, 64).transpose(1, 2)
+    kh = k.view(B, Nk, Hkv, 64).transpose(1, 2)
+    vh = v.view(B, Nk, Hkv, 64).transpose(1, 2)
+    if rope is not None:
+        qh = _rope_ref(qh, *rope)
+        kh = _rope_ref(kh, *rope)
+    if H != Hkv:
+        kh = kh.repeat_interleave(H // Hkv, 1)
+        vh = vh.repeat_interleave(H // Hkv, 1)
+    dots = qh @ kh.transpose(-1, -2) / 8.0
+    if mask is not None:
+        dots = dots.masked_fill(~mask[:, None, None, :], -torch.finfo(dots.dtype).max)
+    o = dots.softmax(-1) @ vh
+    return o.transpose(1, 2).reshape(B, Nq, H * 64)
+
+
+@pytest.mark.parametrize("N,use_rope,use_mask", [(126, True, False), (126, True, True), (40, False, False),
+                                                  (300, True, True), (128, True, False)])
+def test_self_attention_fwd_bwd(ops, dev, N, use_rope, use_mask):
+    B, H = 2, 3
+    D = H * 64
+    qkv = (_mk((B, N, 3 * D), dev, seed=40) * 0.8).bfloat16()
+    dout = _mk((B, N, D), dev, seed=41).bfloat16()
+    rope = _rope_tables(N, dev) if use_rope else None
+    mask = None
+    if use_mask:
+        mask = torch.rand(B, N, device=dev) > 0.25
+        mask[:, 0] = True
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr.chunk(3, -1)
+    ref = _attn_ref(q, k, v, mask, rope, H, H)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(qkv, qkv, qkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D, ldv=3 * D, v_off=2 * D,
+                                 B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask)
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(qkv, qkv, qkv, out, dout, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
+                      ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask)
+    g = qr.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel_l2(dqkv[..., sl], g[..., sl])
+        assert e < 2e-2, (name, e)
+
+
+@pytest.mark.parametrize("Nq,Nk", [(126, 130), (126, 7), (260, 200)])
+def test_cross_attention_gqa_fwd_bwd(ops, dev, Nq, Nk):
+    B, H, Hkv = 2, 4, 2
+    D, Dc = H * 64, Hkv * 64
+    q = (_mk((B, Nq, D), dev, seed=42) * 0.8).bfloat16()
+    kv = (_mk((B, Nk, 2 * Dc), dev, seed=43) * 0.8).bfloat16()
+    dout = _mk((B, Nq, D), dev, seed=44).bfloat16()
+    mask = torch.rand(B, Nk, device=dev) > 0.2
+    mask[:, 0] = True
+    qr = q.float().requires_grad_(True)
+    kvr = kv.float().requires_grad_(True)
+    k, v = kvr.chunk(2, -1)
+    ref = _attn_ref(qr, k, v, mask, None, H, Hkv)
+    ref.backward(dout.float())
+    out, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc,
+                                 B=B, H=H, Hkv=Hkv, Nq=Nq, Nk=Nk, key_mask=mask)
+    assert rel_l2(out, ref) < 1e-2
+    dq = torch.zeros_like(q)
+    dkv = torch.zeros_like(kv)
+    ops.attention_bwd(q, kv, kv, out, dout, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
+                      v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=Nq, Nk=Nk, key_mask=mask)
+    assert rel_l2(dq, qr.grad) < 2e-2
+    assert rel_l2(dkv, kvr.grad) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def _wn(v, g):
+    return g.view(-1, 1, 1) * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,stride,dil,L", [(2, 128, 7, 1, 1, 300), (64, 64, 7, 1, 9, 200),
+                                                      (64, 128, 4, 2, 1, 257), (128, 64, 16, 8, 1, 512),
+                                                      (96, 40, 3, 1, 1, 77), (32, 32, 1, 1, 1, 130)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv1d(ops, dev, Cin, Cout, K, stride, dil, L, act):
+    from kalle_audio_amd import conv_ops
+    B = 2
+    pad = math.ceil(stride / 2) if stride > 1 else dil * (K - 1) // 2
+    x = _mk((B, Cin, L), dev, seed=50)
+    v = _mk((Cout, Cin, K), dev, seed=51) * 0.2
+    g = 1 + 0.1 * _mk((Cout,), dev, seed=52)
+    bias = _mk((Cout,), dev, seed=53)
+    alpha = 0.3 * _mk((Cin,), dev, seed=54)
+    beta = 0.3 * _mk((Cin,), dev, seed=55)
+    w = _wn(v, g)
+    xa = x
+    if act == 1:
+        xa = x + torch.sin(x * alpha.exp()[None, :, None]) ** 2 / (beta.exp()[None, :, None] + 1e-9)
+    elif act == 2:
+        xa = F.elu(x)
+    ref = F.conv1d(xa, w, bias, stride=stride, padding=pad, dilation=dil)
+    wp = conv_ops.weight_norm_fold(v, g, transposed=False)
+    res = _mk(tuple(ref.shape), dev, seed=56) if (stride == 1 and Cin == Cout) else None
+    y = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, dilation=dil, act=act,
+                        alpha=alpha, beta=beta, residual=res, post=1)
+    r = ref + res if res is not None else ref
+    assert rel_l2(y, torch.tanh(r)) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,stride,L", [(128, 64, 2, 100), (64, 32, 4, 130), (64, 48, 8, 65), (32, 16, 5, 40)])
+def test_conv_transpose1d(ops, dev, Cin, Cout, stride, L):
+    from kalle_audio_amd import conv_ops
+    B = 2
+    K = 2 * stride + stride % 2
+    pad = math.ceil(stride / 2)
+    x = _mk((B, Cin, L), dev, seed=60)
+    v = _mk((Cin, Cout, K), dev, seed=61) * 0.2
+    g = 1 + 0.1 * _mk((Cin,), dev, seed=62)
+    bias = _mk((Cout,), dev, seed=63)
+    alpha = 0.3 * _mk((Cin,), dev, seed=64)
+    beta = 0.3 * _mk((Cin,), dev, seed=65)
+    w = _wn(v, g)
+    xa = x + torch.sin(x * alpha.exp()[None, :, None]) ** 2 / (beta.exp()[None, :, None] + 1e-9)
+    ref = F.conv_transpose1d(xa, w, bias, stride=stride, padding=pad)
+    wp = conv_ops.weight_norm_fold(v, g, transposed=True)
+    y = conv_ops.conv_transpose1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=1, alpha=alpha,
+                                  beta=beta)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 2e-5
+
+
+def test_snake(ops, dev):
+    from kalle_audio_amd import conv_ops
+    x = _mk((2, 8, 100), dev, seed=70)
+    a = 0.3 * _mk((8,), dev, seed=71)
+    b = 0.3 * _mk((8,), dev, seed=72)
+    ref = x + torch.sin(x * a.exp()[None, :, None]) ** 2 / (b.exp()[None, :, None] + 1e-9)
+    assert rel_l2(conv_ops.snake_beta(x, a, b), ref) < 1e-6
