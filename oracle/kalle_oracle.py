@@ -1,0 +1,483 @@
+"""CPU fp32 ORACLE for the kalle-audio DiT / audio-VAE hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch restatement (plain torch fp32 on the CPU, functional style over state dicts that use
+the reference's parameter names) of the algorithm in /root/reference/stable_audio_tools.  Each function cites the
+reference file:line it follows.  It is pinned against golden vectors produced by running the reference itself in
+the build container (tests/golden/make_golden.py -> tests/golden/*.npz; checked in tests/test_oracle_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product path
+(kalle_audio_amd/*) never does: it runs hand-written HIP kernels and fails loudly without them.
+
+Parity status: PINNED for every function below by the committed fixtures, except `snake`-free statements marked
+otherwise.  Third-party arithmetic that enters: WNConv1d/WNConvTranspose1d == torch.nn.utils.weight_norm over
+Conv1d/ConvTranspose1d (descript-audio-codec `dac.nn.layers`, version unpinned in the reference).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------- small pieces
+def layer_norm(x, gamma, beta=None, eps=1e-5):
+    """transformer.py:173-192: F.layer_norm over the last dim with gamma and an (optional) beta buffer."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    y = (x - mu) * torch.rsqrt(var + eps) * gamma
+    return y + beta if beta is not None else y
+
+
+def rms_norm(x, scale, eps=1e-6):
+    """blocks.py:268-272 (RMSNorm 285-299): x * scale * rsqrt(mean(x^2)+eps), statistics in fp32."""
+    ms = (x.float() ** 2).mean(-1, keepdim=True)
+    return x * (scale.float() * torch.rsqrt(ms + eps)).to(x.dtype)
+
+
+def snake_beta(x, alpha, beta, logscale=True):
+    """blocks.py:301-339: x + sin^2(x*a)/(b+1e-9), a,b = exp(param) per channel; x is (B, C, L)."""
+    a = alpha[None, :, None]
+    b = beta[None, :, None]
+    if logscale:
+        a, b = a.exp(), b.exp()
+    return x + (1.0 / (b + 1e-9)) * torch.sin(x * a) ** 2
+
+
+def fourier_features(t, weight):
+    """blocks.py:84-93: f = 2 pi t W^T ; cat(cos f, sin f).  t: [B,1], weight: [F/2, 1]."""
+    f = 2 * math.pi * t @ weight.t()
+    return torch.cat([f.cos(), f.sin()], -1)
+
+
+def rotary_freqs(n, rot_dim=32, base=10000.0):
+    """transformer.py:89-138: inv_freq over rot_dim, freqs = cat(pos x inv_freq, twice) -> [n, rot_dim]."""
+    inv = 1.0 / (base ** (torch.arange(0, rot_dim, 2).float() / rot_dim))
+    f = torch.arange(n).float()[:, None] * inv[None, :]
+    return torch.cat([f, f], -1)
+
+
+def apply_rotary(t, freqs):
+    """transformer.py:146-170: partial rotary (GPT-J style) on the first freqs.shape[-1] dims, fp32."""
+    rot = freqs.shape[-1]
+    n = t.shape[-2]
+    fr = freqs[-n:]
+    tr, tu = t[..., :rot], t[..., rot:]
+    half = rot // 2
+    rh = torch.cat([-tr[..., half:], tr[..., :half]], -1)
+    return torch.cat([tr * fr.cos() + rh * fr.sin(), tu], -1)
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y + b if b is not None else y
+
+
+def _sub(sd, prefix):
+    pl = len(prefix)
+    return {k[pl:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+# ---------------------------------------------------------------------------------------------- attention / FF
+def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, dim_heads=64):
+    """transformer.py:396-547 (einsum / fp32-softmax branch 502-530, which is what the reference runs on CPU).
+    sd keys: to_qkv.weight | to_q.weight,to_kv.weight ; to_out.weight"""
+    B, N, D = x.shape
+    h = D // dim_heads
+    if "to_q.weight" in sd:
+        kv_in = context if context is not None else x
+        q = linear(x, sd["to_q.weight"])
+        k, v = linear(kv_in, sd["to_kv.weight"]).chunk(2, -1)
+        kv_h = k.shape[-1] // dim_heads
+    else:
+        q, k, v = linear(x, sd["to_qkv.weight"]).chunk(3, -1)
+        kv_h = h
+    q = q.view(B, N, h, dim_heads).transpose(1, 2)
+    k = k.reshape(B, -1, kv_h, dim_heads).transpose(1, 2)
+    v = v.reshape(B, -1, kv_h, dim_heads).transpose(1, 2)
+    if rotary is not None and context is None:       # 430-444: self-attention only
+        q = apply_rotary(q.float(), rotary)
+        k = apply_rotary(k.float(), rotary)
+    in_mask = context_mask                            # 446-462
+    if in_mask is None and context is None:
+        in_mask = mask
+    if h != kv_h:                                     # 505-508 repeat_interleave
+        k = k.repeat_interleave(h // kv_h, 1)
+        v = v.repeat_interleave(h // kv_h, 1)
+    dots = (q @ k.transpose(-1, -2)) * (dim_heads ** -0.5)
+    if in_mask is not None:
+        dots = dots.masked_fill(~in_mask[:, None, None, :], -torch.finfo(dots.dtype).max)
+    attn = dots.softmax(-1)
+    out = (attn @ v).transpose(1, 2).reshape(B, N, D)
+    out = linear(out, sd["to_out.weight"])
+    if mask is not None:                              # 543-545 zero padded query rows
+        out = out.masked_fill(~mask[:, :, None], 0.0)
+    return out
+
+
+def feed_forward(sd, x):
+    """transformer.py:196-269: SwiGLU: proj (bias) -> x*silu(gate) -> linear_out (bias). keys ff.0.proj.*, ff.2.*"""
+    hdn = linear(x, sd["ff.0.proj.weight"], sd["ff.0.proj.bias"])
+    a, g = hdn.chunk(2, -1)
+    return linear(a * F.silu(g), sd["ff.2.weight"], sd["ff.2.bias"])
+
+
+def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_mask=None, rotary=None, dim_heads=64):
+    """transformer.py:649-695.  adaLN branch when the block has to_scale_shift_gate and global_cond is given."""
+    ln = lambda pre, t: layer_norm(t, sd[pre + ".gamma"], sd.get(pre + ".beta"))
+    sa = _sub(sd, "self_attn.")
+    ff = _sub(sd, "ff.")
+    if "to_scale_shift_gate.1.weight" in sd and global_cond is not None:
+        mod = linear(F.silu(global_cond), sd["to_scale_shift_gate.1.weight"]).unsqueeze(1)
+        sc_s, sh_s, g_s, sc_f, sh_f, g_f = mod.chunk(6, -1)
+        res = x
+        hx = ln("pre_norm", x) * (1 + sc_s) + sh_s
+        hx = attention(sa, hx, mask=mask, rotary=rotary, dim_heads=dim_heads)
+        x = hx * torch.sigmoid(1 - g_s) + res
+        if context is not None:
+            x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
+                              context_mask=context_mask, dim_heads=dim_heads)
+        res = x
+        hx = ln("ff_norm", x) * (1 + sc_f) + sh_f
+        x = feed_forward(ff, hx) * torch.sigmoid(1 - g_f) + res
+    else:
+        x = x + attention(sa, ln("pre_norm", x), mask=mask, rotary=rotary, dim_heads=dim_heads)
+        if context is not None:
+            x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
+                              context_mask=context_mask, dim_heads=dim_heads)
+        x = x + feed_forward(ff, ln("ff_norm", x))
+    return x
+
+
+def continuous_transformer(sd, x, depth, mask=None, prepend_embeds=None, prepend_mask=None, global_cond=None,
+                           context=None, context_mask=None, dim_heads=64):
+    """transformer.py:758-812: project_in, prepend (+mask cat 776-787), rotary over the full length, blocks, project_out."""
+    B, T = x.shape[:2]
+    if "project_in.weight" in sd:
+        x = linear(x, sd["project_in.weight"])
+    if prepend_embeds is not None:
+        P = prepend_embeds.shape[1]
+        x = torch.cat([prepend_embeds, x], 1)
+        if prepend_mask is not None or mask is not None:
+            mask = mask if mask is not None else torch.ones(B, T, dtype=torch.bool)
+            prepend_mask = prepend_mask if prepend_mask is not None else torch.ones(B, P, dtype=torch.bool)
+            mask = torch.cat([prepend_mask, mask], -1)
+    rot = rotary_freqs(x.shape[1], max(dim_heads // 2, 32))
+    for i in range(depth):
+        x = transformer_block(_sub(sd, f"layers.{i}."), x, context=context, global_cond=global_cond, mask=mask,
+                              context_mask=context_mask, rotary=rot, dim_heads=dim_heads)
+    if "project_out.weight" in sd:
+        x = linear(x, sd["project_out.weight"])
+    return x
+
+
+# ---------------------------------------------------------------------------------------------- DiT
+def _mlp2(sd, pre, x, bias):
+    x = linear(x, sd[pre + ".0.weight"], sd.get(pre + ".0.bias") if bias else None)
+    return linear(F.silu(x), sd[pre + ".2.weight"], sd.get(pre + ".2.bias") if bias else None)
+
+
+def dit_inner(sd, cfg, x, t, mask=None, cross_attn_cond=None, cross_attn_cond_mask=None, global_embed=None,
+              prepend_cond=None, prepend_cond_mask=None):
+    """dit.py:135-229 (_forward), continuous_transformer branch. cfg: dict(depth, num_heads, embed_dim,
+    global_cond_type)."""
+    D = cfg["embed_dim"]
+    dh = D // cfg["num_heads"]
+    if cross_attn_cond is not None:
+        cross_attn_cond = _mlp2(sd, "to_cond_embed", cross_attn_cond, False)
+    if global_embed is not None:
+        global_embed = _mlp2(sd, "to_global_embed", global_embed, False)
+    prepend_inputs, prepend_mask, plen = None, None, 0
+    if prepend_cond is not None:
+        prepend_inputs = _mlp2(sd, "to_prepend_embed", prepend_cond, False)
+        prepend_mask = prepend_cond_mask
+    temb = _mlp2(sd, "to_timestep_embed", fourier_features(t[:, None], sd["timestep_features.weight"]), True)
+    global_embed = temb if global_embed is None else global_embed + temb
+    gtype = cfg.get("global_cond_type", "prepend")
+    if gtype == "prepend":
+        ones = torch.ones(x.shape[0], 1, dtype=torch.bool)
+        if prepend_inputs is None:
+            prepend_inputs, prepend_mask = global_embed.unsqueeze(1), ones
+        else:
+            prepend_inputs = torch.cat([prepend_inputs, global_embed.unsqueeze(1)], 1)
+            prepend_mask = torch.cat([prepend_mask, ones], 1)
+        plen = prepend_inputs.shape[1]
+    x = F.conv1d(x, sd["preprocess_conv.weight"]) + x           # dit.py:197
+    x = x.transpose(1, 2)                                        # b c t -> b t c
+    out = continuous_transformer(_sub(sd, "transformer."), x, cfg["depth"], mask=mask, prepend_embeds=prepend_inputs,
+                                 prepend_mask=prepend_mask, global_cond=global_embed if gtype == "adaLN" else None,
+                                 context=cross_attn_cond, context_mask=cross_attn_cond_mask, dim_heads=dh)
+    out = out.transpose(1, 2)[:, :, plen:]
+    return F.conv1d(out, sd["postprocess_conv.weight"]) + out   # dit.py:224
+
+
+def dit_forward(sd, cfg, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
+                negative_cross_attn_mask=None, global_embed=None, prepend_cond=None, prepend_cond_mask=None,
+                cfg_scale=1.0, scale_phi=0.0, mask=None):
+    """dit.py:231-379 with cfg_dropout_prob = 0 (the dropout draw is the only stochastic part and is exercised
+    separately).  Note dit.py:254-257: the cross-attention mask is dropped."""
+    cross_attn_cond_mask = None
+    if cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None):
+        bx = torch.cat([x, x], 0)
+        bt = torch.cat([t, t], 0)
+        bg = torch.cat([global_embed, global_embed], 0) if global_embed is not None else None
+        bc = None
+        if cross_attn_cond is not None:
+            null = torch.zeros_like(cross_attn_cond)
+            if negative_cross_attn_cond is not None:
+                neg = negative_cross_attn_cond
+                if negative_cross_attn_mask is not None:
+                    neg = torch.where(negative_cross_attn_mask.bool().unsqueeze(2), neg, null)
+                bc = torch.cat([cross_attn_cond, neg], 0)
+            else:
+                bc = torch.cat([cross_attn_cond, null], 0)
+        bp, bpm = None, None
+        if prepend_cond is not None:
+            bp = torch.cat([prepend_cond, torch.zeros_like(prepend_cond)], 0)
+            if prepend_cond_mask is not None:
+                bpm = torch.cat([prepend_cond_mask, prepend_cond_mask], 0)
+        bm = torch.cat([mask, mask], 0) if mask is not None else None
+        bo = dit_inner(sd, cfg, bx, bt, mask=bm, cross_attn_cond=bc, global_embed=bg, prepend_cond=bp,
+                       prepend_cond_mask=bpm)
+        cond, uncond = bo.chunk(2, 0)
+        out = uncond + (cond - uncond) * cfg_scale
+        if scale_phi != 0.0:                                      # CFG rescale, dit.py:354-357
+            out = scale_phi * (out * (cond.std(1, keepdim=True) / out.std(1, keepdim=True))) + (1 - scale_phi) * out
+        return out
+    return dit_inner(sd, cfg, x, t, mask=mask, cross_attn_cond=cross_attn_cond,
+                     cross_attn_cond_mask=cross_attn_cond_mask, global_embed=global_embed, prepend_cond=prepend_cond,
+                     prepend_cond_mask=prepend_cond_mask)
+
+
+# ---------------------------------------------------------------------------------------------- train step / samplers
+def alphas_sigmas(t, objective="v"):
+    """inference/sampling.py:8-11 ("v") ; training/diffusion.py:367-368 (rectified flow)."""
+    if objective == "v":
+        return torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
+    return 1 - t, t
+
+
+def diffuse(x, noise, t, objective="v"):
+    """training/diffusion.py:371-379: x_t = x*alpha + n*sigma ; target = n*alpha - x*sigma | n - x."""
+    a, s = alphas_sigmas(t, objective)
+    a, s = a[:, None, None], s[:, None, None]
+    xt = x * a + noise * s
+    target = noise * a - x * s if objective == "v" else noise - x
+    return xt, target
+
+
+def mse_loss(output, target, mask=None, weight=1.0):
+    """training/losses/losses.py:53-69: elementwise MSE, optional [B,T] bool mask broadcast over channels, mean."""
+    l = (output - target) ** 2
+    if mask is not None:
+        m = mask.unsqueeze(1) if mask.dim() == 2 else mask
+        m = m.expand(-1, l.shape[1], -1) if m.shape[1] != l.shape[1] else m
+        l = l[m]
+    return weight * l.mean()
+
+
+def train_step_loss(sd, cfg, latents, noise, t, objective="v", padding_mask=None, **cond):
+    """training/diffusion.py:365-399 with explicit t and noise (that is what makes parity seed-free)."""
+    xt, target = diffuse(latents, noise, t, objective)
+    out = dit_forward(sd, cfg, xt, t, **cond)
+    return mse_loss(out, target, padding_mask), out, xt, target
+
+
+def sample_ddim(model_fn, x, steps, eta=0.0):
+    """inference/sampling.py:47-86 (v-diffusion DDIM; eta = 0 path is deterministic)."""
+    ts = x.new_ones([x.shape[0]])
+    t = torch.linspace(1, 0, steps + 1)[:-1]
+    al, si = alphas_sigmas(t)
+    pred = x
+    for i in range(steps):
+        v = model_fn(x, ts * t[i]).float()
+        pred = x * al[i] - v * si[i]
+        eps = x * si[i] + v * al[i]
+        if i < steps - 1:
+            dd = eta * (si[i + 1] ** 2 / si[i] ** 2).sqrt() * (1 - al[i] ** 2 / al[i + 1] ** 2).sqrt()
+            adj = (si[i + 1] ** 2 - dd ** 2).sqrt()
+            x = pred * al[i + 1] + eps * adj
+            if eta:
+                x = x + torch.randn_like(x) * dd
+    return pred
+
+
+def sample_euler(model_fn, x, steps, sigma_max=1.0):
+    """inference/sampling.py:24-45 (rectified-flow Euler)."""
+    t = torch.linspace(sigma_max, 0, steps + 1)
+    for tc, tp in zip(t[:-1], t[1:]):
+        x = x + (tp - tc) * model_fn(x, tc * torch.ones(x.shape[0], dtype=x.dtype))
+    return x
+
+
+# ---------------------------------------------------------------------------------------------- Oobleck VAE
+def wn_weight(sd, pre):
+    """torch weight_norm (dim=0): w = g * v / ||v|| with the norm over every dim but 0 (dac.nn.layers.WNConv1d)."""
+    v, g = sd[pre + ".weight_v"], sd[pre + ".weight_g"]
+    return g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+
+
+def _act(sd, pre, x, use_snake):
+    return snake_beta(x, sd[pre + ".alpha"], sd[pre + ".beta"]) if use_snake else F.elu(x)
+
+
+def residual_unit(sd, x, dilation, use_snake):
+    """autoencoders.py:39-62: x + conv1(act(conv7_dilated(act(x))))  keys layers.{0,1,2,3}"""
+    h = _act(sd, "layers.0", x, use_snake)
+    h = F.conv1d(h, wn_weight(sd, "layers.1"), sd["layers.1.bias"], dilation=dilation, padding=3 * dilation)
+    h = _act(sd, "layers.2", h, use_snake)
+    h = F.conv1d(h, wn_weight(sd, "layers.3"), sd["layers.3.bias"])
+    return x + h
+
+
+def encoder_block(sd, x, stride, use_snake):
+    """autoencoders.py:64-81: RU(1,3,9) -> act -> strided conv k=2s pad=ceil(s/2). keys layers.{0..4}"""
+    for i, d in enumerate((1, 3, 9)):
+        x = residual_unit(_sub(sd, f"layers.{i}."), x, d, use_snake)
+    x = _act(sd, "layers.3", x, use_snake)
+    return F.conv1d(x, wn_weight(sd, "layers.4"), sd["layers.4.bias"], stride=stride, padding=math.ceil(stride / 2))
+
+
+def decoder_block(sd, x, stride, use_snake):
+    """autoencoders.py:83-114: act -> transposed conv k=2s+s%2 -> RU(1,3,9). keys layers.{0..4}"""
+    x = _act(sd, "layers.0", x, use_snake)
+    x = F.conv_transpose1d(x, wn_weight(sd, "layers.1"), sd["layers.1.bias"], stride=stride,
+                           padding=math.ceil(stride / 2))
+    for i, d in enumerate((1, 3, 9)):
+        x = residual_unit(_sub(sd, f"layers.{i + 2}."), x, d, use_snake)
+    return x
+
+
+def oobleck_encoder(sd, x, strides, use_snake):
+    """autoencoders.py:116-147"""
+    x = F.conv1d(x, wn_weight(sd, "layers.0"), sd["layers.0.bias"], padding=3)
+    for i, s in enumerate(strides):
+        x = encoder_block(_sub(sd, f"layers.{i + 1}."), x, s, use_snake)
+    n = len(strides)
+    x = _act(sd, f"layers.{n + 1}", x, use_snake)
+    return F.conv1d(x, wn_weight(sd, f"layers.{n + 2}"), sd[f"layers.{n + 2}.bias"], padding=1)
+
+
+def oobleck_decoder(sd, z, strides, use_snake, final_tanh=True):
+    """autoencoders.py:150-191 (blocks run over reversed strides; last conv has no bias)"""
+    x = F.conv1d(z, wn_weight(sd, "layers.0"), sd["layers.0.bias"], padding=3)
+    n = len(strides)
+    for j, s in enumerate(reversed(strides)):
+        x = decoder_block(_sub(sd, f"layers.{j + 1}."), x, s, use_snake)
+    x = _act(sd, f"layers.{n + 1}", x, use_snake)
+    x = F.conv1d(x, wn_weight(sd, f"layers.{n + 2}"), None, padding=3)
+    return torch.tanh(x) if final_tanh else x
+
+
+def pretransform_encode(sd, wav, strides, use_snake, scale=1.0):
+    """pretransforms.py:50-61 + autoencoders.py:275-318 + bottleneck.py:85-107 (VAE bottleneck is a pass-through in
+    this reference: the encoder output mean||scale is returned as is), then / scale."""
+    return oobleck_encoder(_sub(sd, "encoder."), wav, strides, use_snake) / scale
+
+
+def pretransform_decode(sd, z, strides, use_snake, scale=1.0, final_tanh=True):
+    """pretransforms.py:63-75 + autoencoders.py:320-361: z * scale -> decoder."""
+    return oobleck_decoder(_sub(sd, "decoder."), z * scale, strides, use_snake, final_tanh)
+
+
+# ---------------------------------------------------------------------------------------------- parameter shapes
+def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix=""):
+    """(name, shape) list of one TransformerBlock (transformer.py:585-647)"""
+    s = [(prefix + "pre_norm.gamma", (D,)), (prefix + "self_attn.to_qkv.weight", (3 * D, D)),
+         (prefix + "self_attn.to_out.weight", (D, D))]
+    if dim_context is not None:
+        s += [(prefix + "cross_attend_norm.gamma", (D,)), (prefix + "cross_attn.to_q.weight", (D, D)),
+              (prefix + "cross_attn.to_kv.weight", (2 * dim_context, dim_context)),
+              (prefix + "cross_attn.to_out.weight", (D, D))]
+    s += [(prefix + "ff_norm.gamma", (D,)), (prefix + "ff.ff.0.proj.weight", (8 * D, D)),
+          (prefix + "ff.ff.0.proj.bias", (8 * D,)), (prefix + "ff.ff.2.weight", (D, 4 * D)),
+          (prefix + "ff.ff.2.bias", (D,))]
+    if global_cond_dim:
+        s += [(prefix + "to_scale_shift_gate.1.weight", (6 * D, global_cond_dim))]
+    return s
+
+
+def continuous_transformer_shapes(D, depth, dim_in=None, dim_out=None, dim_context=None, global_cond_dim=None,
+                                  prefix=""):
+    s = []
+    if dim_in is not None:
+        s.append((prefix + "project_in.weight", (D, dim_in)))
+    if dim_out is not None:
+        s.append((prefix + "project_out.weight", (dim_out, D)))
+    for i in range(depth):
+        s += block_shapes(D, dim_context=dim_context, global_cond_dim=global_cond_dim, prefix=f"{prefix}layers.{i}.")
+    return s
+
+
+def dit_shapes(io_channels, embed_dim, depth, cond_token_dim=0, global_cond_dim=0, prepend_cond_dim=0,
+               global_cond_type="prepend", project_cond_tokens=True):
+    """dit.py:14-133 parameter inventory (continuous_transformer branch)."""
+    D = embed_dim
+    s = [("timestep_features.weight", (128, 1)), ("to_timestep_embed.0.weight", (D, 256)),
+         ("to_timestep_embed.0.bias", (D,)), ("to_timestep_embed.2.weight", (D, D)), ("to_timestep_embed.2.bias", (D,))]
+    ce = 0
+    if cond_token_dim > 0:
+        ce = D if project_cond_tokens else cond_token_dim
+        s += [("to_cond_embed.0.weight", (ce, cond_token_dim)), ("to_cond_embed.2.weight", (ce, ce))]
+    if global_cond_dim > 0:
+        s += [("to_global_embed.0.weight", (D, global_cond_dim)), ("to_global_embed.2.weight", (D, D))]
+    if prepend_cond_dim > 0:
+        s += [("to_prepend_embed.0.weight", (D, prepend_cond_dim)), ("to_prepend_embed.2.weight", (D, D))]
+    s += continuous_transformer_shapes(D, depth, dim_in=io_channels, dim_out=io_channels,
+                                       dim_context=ce if cond_token_dim > 0 else None,
+                                       global_cond_dim=D if global_cond_type == "adaLN" else None,
+                                       prefix="transformer.")
+    s += [("preprocess_conv.weight", (io_channels, io_channels, 1)),
+          ("postprocess_conv.weight", (io_channels, io_channels, 1))]
+    return s
+
+
+def _wnconv_shapes(pre, cout, cin, k, bias=True, transposed=False):
+    wshape = (cin, cout, k) if transposed else (cout, cin, k)
+    s = [(pre + ".weight_g", (wshape[0], 1, 1)), (pre + ".weight_v", wshape)]
+    if bias:
+        s.insert(0, (pre + ".bias", (cout,)))
+    return s
+
+
+def _act_shapes(pre, c, use_snake):
+    return [(pre + ".alpha", (c,)), (pre + ".beta", (c,))] if use_snake else []
+
+
+def residual_unit_shapes(c, use_snake, prefix=""):
+    return (_act_shapes(prefix + "layers.0", c, use_snake) + _wnconv_shapes(prefix + "layers.1", c, c, 7) +
+            _act_shapes(prefix + "layers.2", c, use_snake) + _wnconv_shapes(prefix + "layers.3", c, c, 1))
+
+
+def encoder_block_shapes(cin, cout, stride, use_snake, prefix=""):
+    s = []
+    for i in range(3):
+        s += residual_unit_shapes(cin, use_snake, f"{prefix}layers.{i}.")
+    return s + _act_shapes(prefix + "layers.3", cin, use_snake) + _wnconv_shapes(prefix + "layers.4", cout, cin, 2 * stride)
+
+
+def decoder_block_shapes(cin, cout, stride, use_snake, prefix=""):
+    s = _act_shapes(prefix + "layers.0", cin, use_snake)
+    s += _wnconv_shapes(prefix + "layers.1", cout, cin, 2 * stride + stride % 2, transposed=True)
+    for i in range(3):
+        s += residual_unit_shapes(cout, use_snake, f"{prefix}layers.{i + 2}.")
+    return s
+
+
+def oobleck_encoder_shapes(in_channels, channels, latent_dim, c_mults, strides, use_snake, prefix=""):
+    cm = [1] + list(c_mults)
+    s = _wnconv_shapes(prefix + "layers.0", cm[0] * channels, in_channels, 7)
+    for i, st in enumerate(strides):
+        s += encoder_block_shapes(cm[i] * channels, cm[i + 1] * channels, st, use_snake, f"{prefix}layers.{i + 1}.")
+    n = len(strides)
+    s += _act_shapes(f"{prefix}layers.{n + 1}", cm[-1] * channels, use_snake)
+    return s + _wnconv_shapes(f"{prefix}layers.{n + 2}", latent_dim, cm[-1] * channels, 3)
+
+
+def oobleck_decoder_shapes(out_channels, channels, latent_dim, c_mults, strides, use_snake, prefix=""):
+    cm = [1] + list(c_mults)
+    s = _wnconv_shapes(prefix + "layers.0", cm[-1] * channels, latent_dim, 7)
+    n = len(strides)
+    for j, i in enumerate(range(n, 0, -1)):
+        s += decoder_block_shapes(cm[i] * channels, cm[i - 1] * channels, strides[i - 1], use_snake,
+                                  f"{prefix}layers.{j + 1}.")
+    s += _act_shapes(f"{prefix}layers.{n + 1}", cm[0] * channels, use_snake)
+    return s + _wnconv_shapes(f"{prefix}layers.{n + 2}", out_channels, cm[0] * channels, 7, bias=False)

@@ -20,7 +20,9 @@ def make_param(name, shape, seed):
     rng = np.random.Generator(np.random.PCG64(_seed_for(name, seed)))
     n = rng.standard_normal(size=tuple(shape), dtype=np.float64)
     leaf = name.split(".")[-1]
-    if leaf in ("gamma", "weight_g", "scale"):
+    if leaf == "weight_g":
+        v = 0.5 + 0.05 * n  # keeps the deep conv stacks (and the final tanh) out of saturation
+    elif leaf in ("gamma", "scale"):
         v = 1.0 + 0.1 * n
     elif len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))

@@ -51,7 +51,6 @@ def install_stubs():
     ta.transforms = mod("torchaudio.transforms")
     mod("k_diffusion")
     mod("einops_exts", rearrange_many=None)
-    mod("tqdm", trange=range, tqdm=lambda x, *a, **k: x)
 
 
 def load_seeded(module, seed):

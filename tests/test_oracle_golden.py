@@ -1,0 +1,190 @@
+"""CPU: the oracle (oracle/kalle_oracle.py, own fp32 restatement) against the golden vectors that
+tests/golden/make_golden.py produced by running the reference itself.  Tolerance: fp32, rtol 1e-5-ish
+(relative L2 <= 2e-6 on tensors, 1e-4 relative on gradient digests which include long sums)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import golden_util as gu  # noqa: E402
+import kalle_oracle as ko  # noqa: E402
+
+G = os.path.join(HERE, "golden")
+B, N, D, S, DC, CIO, GD = 2, 125, 128, 7, 64, 16, 32
+
+
+def fx(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.asarray(a)).clone()
+    return t.requires_grad_(True) if grad else t
+
+
+def state(shapes, seed, grad=True):
+    return {k: T(v, grad) for k, v in gu.make_state(shapes, seed).items()}
+
+
+def close(a, b, tol=3e-6):
+    a = a.detach().double() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a)).double()
+    b = torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = ((a - b).norm() / (b.norm() + 1e-30)).item()
+    assert err < tol, err
+
+
+def check_digests(f, sd, prefix="", tol=2e-5):
+    n = 0
+    for k in f.files:
+        if k.startswith(prefix + "digest/"):
+            name = k[len(prefix) + 7:]
+            got = gu.digest(sd[name].grad.numpy())
+            ref = f[k]
+            scale = max(abs(ref[0]), 1e-12)
+            assert np.all(np.abs(got - ref) <= tol * scale + 1e-7), (name, got[:3], ref[:3])
+            n += 1
+        if k.startswith(prefix + "grad/"):
+            name = k[len(prefix) + 5:]
+            close(sd[name].grad, f[k], 1e-5)
+    assert n > 0
+
+
+def test_layernorm_rmsnorm_snake_fourier():
+    f = fx("layernorm")
+    x = T(gu.make_input("x", (B, N, D), 1, 1.5), True)
+    dy = T(gu.make_input("dy", (B, N, D), 1))
+    sd = state([("gamma", (D,))], 1)
+    y = ko.layer_norm(x, sd["gamma"])
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); check_digests(f, sd)
+    f = fx("rmsnorm")
+    x = T(gu.make_input("x", (B, N, D), 2, 1.5), True)
+    sd = state([("scale", (D,))], 2)
+    y = ko.rms_norm(x, sd["scale"])
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); check_digests(f, sd)
+    sd = state([("alpha", (8,)), ("beta", (8,))], 3, False)
+    close(ko.snake_beta(T(gu.make_input("x", (B, 8, 100), 3, 2.0)), sd["alpha"], sd["beta"]), fx("snake_beta")["y"])
+    sd = state([("weight", (128, 1))], 4, False)
+    # FourierFeatures is seeded under its module-local name "weight": N(0,1)/sqrt(fan_in=1)
+    t = T(np.linspace(0.05, 0.95, 6).astype(np.float32))
+    close(ko.fourier_features(t[:, None], sd["weight"]), fx("fourier_features")["y"], 1e-5)
+
+
+def test_attention_self_and_cross():
+    f = fx("attention_self")
+    dy = T(gu.make_input("dy", (B, N, D), 1))
+    x = T(gu.make_input("x", (B, N, D), 5), True)
+    mask = T(gu.make_mask("m", (B, N), 5))
+    sd = state([("to_qkv.weight", (3 * D, D)), ("to_out.weight", (D, D))], 5)
+    y = ko.attention(sd, x, mask=mask, rotary=ko.rotary_freqs(N))
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); check_digests(f, sd)
+    f = fx("attention_cross")
+    x = T(gu.make_input("x", (B, N, D), 6), True)
+    ctx = T(gu.make_input("ctx", (B, S, DC), 6), True)
+    cm = T(gu.make_mask("cm", (B, S), 6))
+    sd = state([("to_q.weight", (D, D)), ("to_kv.weight", (2 * DC, DC)), ("to_out.weight", (D, D))], 6)
+    y = ko.attention(sd, x, context=ctx, context_mask=cm)
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); close(ctx.grad, f["dctx"]); check_digests(f, sd)
+
+
+def test_feedforward():
+    f = fx("feedforward")
+    dy = T(gu.make_input("dy", (B, N, D), 1))
+    x = T(gu.make_input("x", (B, N, D), 7), True)
+    sd = state([("ff.0.proj.weight", (8 * D, D)), ("ff.0.proj.bias", (8 * D,)), ("ff.2.weight", (D, 4 * D)),
+                ("ff.2.bias", (D,))], 7)
+    y = ko.feed_forward(sd, x)
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); check_digests(f, sd)
+
+
+@pytest.mark.parametrize("name,gdim,seed", [("block_plain", None, 8), ("block_adaln", D, 9)])
+def test_transformer_block(name, gdim, seed):
+    f = fx(name)
+    dy = T(gu.make_input("dy", (B, N, D), 1))
+    x = T(gu.make_input("x", (B, N, D), seed), True)
+    ctx = T(gu.make_input("ctx", (B, S, DC), seed), True)
+    sd = state(ko.block_shapes(D, dim_context=DC, global_cond_dim=gdim), seed)
+    gc = T(gu.make_input("g", (B, D), seed), True) if gdim else None
+    y = ko.transformer_block(sd, x, context=ctx, global_cond=gc, rotary=ko.rotary_freqs(N))
+    y.backward(dy)
+    close(y, f["y"]); close(x.grad, f["dx"]); close(ctx.grad, f["dctx"]); check_digests(f, sd)
+    if gdim:
+        close(gc.grad, f["dg"])
+
+
+def test_continuous_transformer():
+    f = fx("continuous_transformer")
+    x = T(gu.make_input("x", (B, N, CIO), 10), True)
+    pre = T(gu.make_input("pre", (B, 1, D), 10), True)
+    ctx = T(gu.make_input("ctx", (B, S, DC), 10), True)
+    sd = state(ko.continuous_transformer_shapes(D, 2, CIO, CIO, DC), 10)
+    y = ko.continuous_transformer(sd, x, 2, prepend_embeds=pre, prepend_mask=torch.ones(B, 1, dtype=torch.bool),
+                                  context=ctx)
+    y.backward(T(gu.make_input("dyo", (B, N + 1, CIO), 10)))
+    close(y, f["y"]); close(x.grad, f["dx"]); close(pre.grad, f["dpre"]); close(ctx.grad, f["dctx"])
+    check_digests(f, sd)
+
+
+@pytest.mark.parametrize("gtype,seed", [("prepend", 11), ("adaLN", 12)])
+def test_dit_train_step_cfg_and_samplers(gtype, seed):
+    f = fx(f"dit_{gtype}")
+    cfg = dict(embed_dim=D, depth=2, num_heads=2, global_cond_type=gtype)
+    shapes = ko.dit_shapes(CIO, D, 2, cond_token_dim=DC, global_cond_dim=GD, global_cond_type=gtype,
+                           project_cond_tokens=False)
+    lat = T(gu.make_input("lat", (B, CIO, N), seed))
+    noise = T(gu.make_input("noise", (B, CIO, N), seed))
+    tt = T(np.array([0.3, 0.85], dtype=np.float32))
+    ctx = T(gu.make_input("ctx", (B, S, DC), seed))
+    cm = T(gu.make_mask("cm", (B, S), seed))
+    gl = T(gu.make_input("glob", (B, GD), seed))
+    pm = T(gu.make_mask("pm", (B, N), seed, 0.7))
+    for obj in ("v", "rectified_flow"):
+        sd = state(shapes, seed)
+        loss, out, xt, tgt = ko.train_step_loss(sd, cfg, lat, noise, tt, obj, cross_attn_cond=ctx,
+                                                cross_attn_cond_mask=cm, global_embed=gl)
+        loss.backward()
+        close(xt, f[f"{obj}/x_t"]); close(tgt, f[f"{obj}/target"]); close(out, f[f"{obj}/output"], 1e-5)
+        assert abs(loss.item() - f[f"{obj}/loss"].item()) < 1e-5 * abs(loss.item())
+        lm = ko.mse_loss(out, tgt, pm)
+        assert abs(lm.item() - f[f"{obj}_masked/loss"].item()) < 1e-5 * abs(lm.item())
+        check_digests(f, sd, prefix=f"{obj}/", tol=5e-5)
+    sd = state(shapes, seed, False)
+    xt = T(f["rectified_flow/x_t"])
+    close(ko.dit_forward(sd, cfg, xt, tt, cross_attn_cond=ctx, global_embed=gl, cfg_scale=3.0, scale_phi=0.5),
+          f["cfg3_phi05/output"], 1e-5)
+    close(ko.dit_forward(sd, cfg, xt, tt, cross_attn_cond=ctx, global_embed=gl, cfg_scale=2.0,
+                         negative_cross_attn_cond=ctx.flip(0), negative_cross_attn_mask=cm), f["cfg2_neg/output"], 1e-5)
+    if gtype == "prepend":
+        x0 = T(gu.make_input("x0", (B, CIO, N), seed))
+        fn = lambda x_, t_: ko.dit_forward(sd, cfg, x_, t_, cross_attn_cond=ctx, global_embed=gl, cfg_scale=3.0)
+        close(ko.sample_ddim(fn, x0, 4), f["sample_ddim4"], 2e-5)
+        close(ko.sample_euler(fn, x0, 4), f["sample_euler4"], 2e-5)
+
+
+@pytest.mark.parametrize("snake", [True, False])
+def test_oobleck(snake):
+    tag = "snake" if snake else "elu"
+    f = fx(f"oobleck_units_{tag}")
+    xx = T(gu.make_input("x", (B, 16, 200), 20, 1.0))
+    y_ru = ko.residual_unit(state(ko.residual_unit_shapes(16, snake), 20, False), xx, 3, snake)
+    y_eb = ko.encoder_block(state(ko.encoder_block_shapes(16, 32, 4, snake), 21, False), xx, 4, snake)
+    y_db = ko.decoder_block(state(ko.decoder_block_shapes(32, 16, 4, snake), 22, False), y_eb, 4, snake)
+    close(y_ru, f["y_ru"]); close(y_eb, f["y_eb"]); close(y_db, f["y_db"])
+    f = fx(f"oobleck_vae_{tag}")
+    shapes = (ko.oobleck_encoder_shapes(2, 8, 8, [1, 2, 4], [2, 4, 5], snake, "encoder.") +
+              ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], snake, "decoder."))
+    sd = state(shapes, 23, False)
+    wav = T(gu.make_input("wav", (B, 2, 1200), 23, 0.5))
+    z = ko.pretransform_encode(sd, wav, [2, 4, 5], snake, scale=0.8)
+    rec = ko.pretransform_decode(sd, z[:, :4], [2, 4, 5], snake, scale=0.8, final_tanh=snake)
+    close(z, f["z"], 1e-5); close(rec, f["rec"], 1e-5)
