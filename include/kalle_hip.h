@@ -51,6 +51,8 @@ typedef struct kalle_gemm_epilogue {
     int32_t c_rows_per_batch;
     int32_t c_batch_rows;
     int32_t c_row_offset;
+    const uint8_t* row_mask; /* [M] or NULL: rows with 0 contribute 0 before the residual add
+                              * (Attention zeroes padded query rows after to_out, transformer.py:543-545) */
 } kalle_gemm_epilogue;
 
 int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
@@ -139,9 +141,21 @@ int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_stride, int64
 /* dtype conversion fp32 <-> bf16 (n elements, n % 8 == 0 not required) */
 int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 
+/* residual-stream gradient -> bf16 GEMM operand, with the adaLN gate backward fused in:
+ *   gb[b,t,n]   = bf16( g[b,t,n] * (gate ? sigmoid(1-gate[b,n]) : 1) * (row_mask ? row_mask[b*T+t] : 1) )
+ *   dgate[b,n]  = -(1 - sigmoid(1-gate[b,n])) * sum_t g[b,t,n]*row_mask * (x_out[b,t,n] - x_in[b,t,n])     (gate != NULL)
+ * (x_out = x_in + branch*sigmoid(1-gate), transformer.py:667-668,681-682; x_out/x_in/dgate unused when gate == NULL) */
+int kalle_grad_cast(const float* g, const float* x_out, const float* x_in, const float* gate, int64_t ldg,
+                    const uint8_t* row_mask, void* gb, float* dgate, int nbatch, int rows_per_batch, int D,
+                    void* stream);
+
 /* timestep Fourier features (blocks.py:84-93): out[b, j] = cos(2 pi t[b] w[j]), out[b, F/2+j] = sin(...) ; out bf16 or fp32 */
 int kalle_fourier_features(const float* t, const float* w, void* out, int out_dtype, int nbatch, int half,
                            void* stream);
+
+/* dw[j] = sum_b 2 pi t[b] * (dout[b, half+j] cos(f) - dout[b, j] sin(f)),  f = 2 pi t[b] w[j]   (dout fp32 [B][2*half]) */
+int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w, float* dw, int nbatch, int half,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Attention (non-causal, optional key mask), LDS-resident K/V tiles, bf16 MFMA, fp32 softmax.

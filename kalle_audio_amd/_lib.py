@@ -30,6 +30,7 @@ class GemmEpilogue(ctypes.Structure):
         ("c_rows_per_batch", ctypes.c_int32),
         ("c_batch_rows", ctypes.c_int32),
         ("c_row_offset", ctypes.c_int32),
+        ("row_mask", ctypes.c_void_p),
     ]
 
 

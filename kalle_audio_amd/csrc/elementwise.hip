@@ -246,6 +246,54 @@ __global__ void fourier_kernel(const float* __restrict__ t, const float* __restr
     }
 }
 
+// ---- residual gradient -> bf16 operand (+ adaLN gate backward); one thread per (batch, column pair) ------
+__global__ __launch_bounds__(256) void grad_cast_kernel(const float* __restrict__ g, const float* __restrict__ xo,
+                                                        const float* __restrict__ xi, const float* __restrict__ gate,
+                                                        int64_t ldg, const uint8_t* __restrict__ rmask,
+                                                        bf16_t* __restrict__ gb, float* __restrict__ dgate, int rpb,
+                                                        int D) {
+    const int b = blockIdx.y;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (col >= D) return;
+    float s0 = 1.f, s1 = 1.f;
+    if (gate) {
+        s0 = sigmoidf_(1.f - gate[(int64_t)b * ldg + col]);
+        s1 = sigmoidf_(1.f - gate[(int64_t)b * ldg + col + 1]);
+    }
+    float a0 = 0.f, a1 = 0.f;
+    for (int t = 0; t < rpb; ++t) {
+        const int64_t row = (int64_t)b * rpb + t;
+        const float m = (rmask && !rmask[row]) ? 0.f : 1.f;
+        const f32x2 gv = *reinterpret_cast<const f32x2*>(g + row * D + col);
+        const float g0 = gv[0] * m, g1 = gv[1] * m;
+        if (gate) {
+            const f32x2 o = *reinterpret_cast<const f32x2*>(xo + row * D + col);
+            const f32x2 i = *reinterpret_cast<const f32x2*>(xi + row * D + col);
+            a0 += g0 * (o[0] - i[0]);
+            a1 += g1 * (o[1] - i[1]);
+        }
+        *reinterpret_cast<uint32_t*>(gb + row * D + col) = pack_bf16x2(g0 * s0, g1 * s1);
+    }
+    if (gate && dgate) {
+        dgate[(int64_t)b * ldg + col] = -(1.f - s0) * a0;
+        dgate[(int64_t)b * ldg + col + 1] = -(1.f - s1) * a1;
+    }
+}
+
+__global__ void fourier_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ t,
+                                   const float* __restrict__ w, float* __restrict__ dw, int nbatch, int half) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    float acc = 0.f;
+    const float wj = w[j];
+    for (int b = 0; b < nbatch; ++b) {
+        const float k = 6.283185307179586f * t[b];
+        const float f = k * wj;
+        acc += k * (dout[(int64_t)b * 2 * half + half + j] * cosf(f) - dout[(int64_t)b * 2 * half + j] * sinf(f));
+    }
+    dw[j] = acc;
+}
+
 // ---- fused Adam / AdamW ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
@@ -389,6 +437,23 @@ extern "C" int kalle_fourier_features(const float* t, const float* w, void* out,
     dim3 grid((nbatch * half + 255) / 256), block(256);
     if (out_dtype == KALLE_F32) hipLaunchKernelGGL((fourier_kernel<true>), grid, block, 0, st, t, w, out, nbatch, half);
     else hipLaunchKernelGGL((fourier_kernel<false>), grid, block, 0, st, t, w, out, nbatch, half);
+    return kalle_check_launch();
+}
+extern "C" int kalle_grad_cast(const float* g, const float* x_out, const float* x_in, const float* gate, int64_t ldg,
+                               const uint8_t* row_mask, void* gb, float* dgate, int nbatch, int rows_per_batch, int D,
+                               void* stream) {
+    if (!g || !gb || nbatch <= 0 || rows_per_batch <= 0 || D <= 0 || (D & 1) || nbatch > 65535) return KALLE_ERR_ARG;
+    if (gate && (!x_out || !x_in)) return KALLE_ERR_ARG;
+    dim3 block(128), grid((D / 2 + 127) / 128, nbatch);
+    hipLaunchKernelGGL(grad_cast_kernel, grid, block, 0, static_cast<hipStream_t>(stream), g, x_out, x_in, gate, ldg,
+                       row_mask, static_cast<bf16_t*>(gb), dgate, rows_per_batch, D);
+    return kalle_check_launch();
+}
+extern "C" int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w, float* dw, int nbatch,
+                                          int half, void* stream) {
+    if (!dout || !t || !w || !dw || nbatch <= 0 || half <= 0) return KALLE_ERR_ARG;
+    hipLaunchKernelGGL(fourier_bwd_kernel, dim3((half + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       dout, t, w, dw, nbatch, half);
     return kalle_check_launch();
 }
 extern "C" int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,

@@ -41,6 +41,7 @@ struct GemmParams {
     int tiles_n;
     float alpha;
     int c_rpb, c_brows, c_roff;
+    const uint8_t* row_mask;
 };
 
 // ---- staging: global -> registers ------------------------------------------------------------
@@ -228,6 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] *= sigmoidf_(1.f - g0[j]); v[4 + j] *= sigmoidf_(1.f - g1[j]); }
         }
+        if (p.row_mask && !p.row_mask[gm]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
         if (p.residual) {
             const float* rp = p.residual + crow * p.ldr + gn;
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp);
@@ -303,6 +308,7 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
         p.residual = ep->residual; p.ldr = ep->ldr;
         p.accumulate = ep->accumulate;
         if (ep->alpha != 0.f) p.alpha = ep->alpha;
+        p.row_mask = ep->row_mask;
         p.c_rpb = ep->c_rows_per_batch; p.c_brows = ep->c_batch_rows; p.c_roff = ep->c_row_offset;
         if (p.accumulate && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
         if ((p.bias && !al16(p.bias)) || (p.gate && (!al16(p.gate) || (p.ldg & 3))) ||

@@ -1,0 +1,271 @@
+"""Forward / backward of the DiT building blocks expressed as sequences of C-ABI kernel launches.
+
+Everything here is "manual autograd": each *_fwd returns the tensors its *_bwd needs, each *_bwd returns input
+and parameter gradients.  The torch.autograd.Function shims in functional.py and the data-parallel trainer in
+engine.py are both thin layers over these functions, so the drop-in modules and the benchmarked train step run
+exactly the same kernels.
+
+Dtype policy: residual stream fp32, GEMM operands bf16, GEMM accumulation fp32, parameter gradients
+fp32.  Reference: stable_audio_tools/models/transformer.py (line numbers per function).
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def bf16_of(p):
+    """bf16 compute copy of an fp32 parameter, re-cast only when the parameter changed (or pinned by the engine)."""
+    pinned = getattr(p, "_kalle_bf16_pinned", None)
+    if pinned is not None:
+        return pinned
+    c = getattr(p, "_kalle_bf16", None)
+    if c is None or c[0] != p._version or c[1].device != p.device:
+        c = (p._version, ops.cast(p.detach().float(), BF16))
+        p._kalle_bf16 = c
+    return c[1]
+
+
+def f32_of(p):
+    d = p.detach()
+    return d if d.dtype == F32 else d.float()
+
+
+def rope_tables(freqs):
+    """freqs: [N, rot] as produced by RotaryEmbedding (cat(f, f)); returns cos/sin [N, rot/2] fp32 for the kernel."""
+    half = freqs.shape[-1] // 2
+    f = freqs[:, :half].float()
+    return f.cos().contiguous(), f.sin().contiguous()
+
+
+def wgrad(dy, x):
+    """dW[N,K] = dy[M,N]^T @ x[M,K] (fp32 out)"""
+    return ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+
+
+def dgrad(dy, w, **kw):
+    """dx[M,K] = dy[M,N] @ w[N,K]"""
+    return ops.gemm(dy, w, b_kmajor=True, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, out_dtype=F32):
+    """transformer.py:419-420, 430-444, 500/514-530, 541-545.  h: bf16 [B*N, D]."""
+    D = H * 64
+    qkv = ops.gemm(h, wqkv)
+    ao, lse = ops.attention_fwd(qkv, qkv, qkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D, ldv=3 * D, v_off=2 * D,
+                                B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+    out = ops.gemm(ao.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, gate=gate, rows_per_batch=N,
+                   row_mask=mask8)
+    return out, (qkv, ao, lse)
+
+
+def self_attn_bwd(gb, h, saved, wqkv, wo, B, N, H, rope, mask8):
+    """gb: bf16 [B*N, D] gradient w.r.t. the to_out GEMM result. Returns dh (bf16), dWqkv, dWo (fp32)."""
+    qkv, ao, lse = saved
+    D = H * 64
+    ao2 = ao.view(B * N, D)
+    dwo = wgrad(gb, ao2)
+    dao = dgrad(gb, wo)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv, qkv, qkv, ao, dao, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
+                      ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+    dwqkv = wgrad(dqkv, h)
+    dh = dgrad(dqkv, wqkv)
+    return dh, dwqkv, dwo
+
+
+def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None):
+    """transformer.py:411-416, 505-508 (GQA), 541.  h: bf16 [B*N, D]; ctx: bf16 [B*S, Dc]."""
+    D = H * 64
+    Dc = ctx.shape[-1]
+    Hkv = Dc // 64
+    q = ops.gemm(h, wq)
+    kv = ops.gemm(ctx, wkv)
+    co, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
+                                Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+    out = ops.gemm(co.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, row_mask=row_mask)
+    return out, (q, kv, co, lse)
+
+
+def cross_attn_bwd(gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_acc=None):
+    """Returns dh (bf16), dctx (fp32 [B*S, Dc], accumulated into dctx_acc when given), dWq, dWkv, dWo."""
+    q, kv, co, lse = saved
+    D = H * 64
+    Dc = ctx.shape[-1]
+    Hkv = Dc // 64
+    co2 = co.view(B * N, D)
+    dwo = wgrad(gb, co2)
+    dco = dgrad(gb, wo)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    ops.attention_bwd(q, kv, kv, co, dco, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
+                      v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+    dwq = wgrad(dq, h)
+    dh = dgrad(dq, wq)
+    dwkv = wgrad(dkv, ctx)
+    if dctx_acc is not None:
+        dctx = dgrad(dkv, wkv, out=dctx_acc, accumulate=True)
+    else:
+        dctx = dgrad(dkv, wkv, out_dtype=F32)
+    return dh, dctx, dwq, dwkv, dwo
+
+
+# ------------------------------------------------------------------------------------------------ feed-forward
+def ff_fwd(h, w1, b1, w2, b2, N, residual=None, gate=None, out_dtype=F32):
+    """transformer.py:216-219 (GLU proj + x*silu(gate)), 252 (linear_out)."""
+    hf = ops.gemm(h, w1, bias=b1)
+    act = ops.swiglu_fwd(hf)
+    out = ops.gemm(act, w2, bias=b2, out_dtype=out_dtype, residual=residual, gate=gate, rows_per_batch=N)
+    return out, (hf, act)
+
+
+def ff_bwd(gb, h, saved, w1, w2, want_bias=True):
+    hf, act = saved
+    dw2 = wgrad(gb, act)
+    db2 = ops.colsum(gb) if want_bias else None
+    dact = dgrad(gb, w2)
+    dhf = ops.swiglu_bwd(dact, hf)
+    dw1 = wgrad(dhf, h)
+    db1 = ops.colsum(dhf) if want_bias else None
+    dh = dgrad(dhf, w1)
+    return dh, dw1, db1, dw2, db2
+
+
+# ------------------------------------------------------------------------------------------------ transformer block
+def block_params(blk):
+    """Gather the kernel-ready views of one TransformerBlock's parameters (bf16 weights, fp32 vectors)."""
+    p = SimpleNamespace()
+    p.g1 = f32_of(blk.pre_norm.gamma)
+    p.beta1 = _beta(blk.pre_norm)
+    p.wqkv = bf16_of(blk.self_attn.to_qkv.weight)
+    p.wo = bf16_of(blk.self_attn.to_out.weight)
+    p.cross = blk.cross_attend
+    if p.cross:
+        p.g2 = f32_of(blk.cross_attend_norm.gamma)
+        p.beta2 = _beta(blk.cross_attend_norm)
+        p.wq = bf16_of(blk.cross_attn.to_q.weight)
+        p.wkv = bf16_of(blk.cross_attn.to_kv.weight)
+        p.wo2 = bf16_of(blk.cross_attn.to_out.weight)
+    p.g3 = f32_of(blk.ff_norm.gamma)
+    p.beta3 = _beta(blk.ff_norm)
+    lin1, lin2 = blk.ff.ff[0].proj, blk.ff.ff[2]
+    p.w1 = bf16_of(lin1.weight)
+    p.b1 = f32_of(lin1.bias) if lin1.bias is not None else None
+    p.w2 = bf16_of(lin2.weight)
+    p.b2 = f32_of(lin2.bias) if lin2.bias is not None else None
+    p.ada = blk.global_cond_dim is not None and blk.global_cond_dim > 0
+    if p.ada:
+        p.wmod = bf16_of(blk.to_scale_shift_gate[1].weight)
+    p.H = blk.dim // blk.dim_heads
+    return p
+
+
+def _beta(norm):
+    b = getattr(norm, "beta", None)
+    if b is None:
+        return None
+    if isinstance(b, torch.nn.Parameter):
+        return f32_of(b)
+    return None  # zero buffer (transformer.py:188): adding it is a no-op
+
+
+BLOCK_PARAM_ORDER = ("pre_norm.gamma", "self_attn.to_qkv.weight", "self_attn.to_out.weight",
+                     "cross_attend_norm.gamma", "cross_attn.to_q.weight", "cross_attn.to_kv.weight",
+                     "cross_attn.to_out.weight", "ff_norm.gamma", "ff.ff.0.proj.weight", "ff.ff.0.proj.bias",
+                     "ff.ff.2.weight", "ff.ff.2.bias", "to_scale_shift_gate.1.weight")
+
+
+def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
+    """transformer.py:649-695.  x: fp32 [B*N, D] residual stream; ctx: bf16 [B*S, Dc] or None;
+    global_cond: fp32 [B, G] or None (adaLN).  Returns (y fp32 [B*N, D], saved)."""
+    D = x.shape[-1]
+    sv = SimpleNamespace(x=x)
+    ada = p.ada and global_cond is not None
+    sc_s = sh_s = g_s = sc_f = sh_f = g_f = None
+    if ada:
+        sv.x_global = global_cond
+        sv.sg = ops.silu_fwd(global_cond)                                   # 641-644 SiLU -> Linear(no bias)
+        sv.sgb = ops.cast(sv.sg, BF16)
+        sv.mod = ops.gemm(sv.sgb, p.wmod, out_dtype=F32)                    # [B, 6D]
+        sc_s, sh_s, g_s, sc_f, sh_f, g_f = (sv.mod[:, i * D:(i + 1) * D] for i in range(6))
+    # self-attention
+    sv.h1, sv.mean1, sv.rstd1 = ops.layernorm_fwd(x, p.g1, p.beta1, sc_s, sh_s, rows_per_batch=N)
+    sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s)
+    xcur = sv.x1
+    # cross-attention (never modulated, 670-671)
+    if p.cross and ctx is not None:
+        sv.h2, sv.mean2, sv.rstd2 = ops.layernorm_fwd(xcur, p.g2, p.beta2)
+        sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur)
+        xcur = sv.x2
+    # feed-forward
+    sv.h3, sv.mean3, sv.rstd3 = ops.layernorm_fwd(xcur, p.g3, p.beta3, sc_f, sh_f, rows_per_batch=N)
+    y, sv.ff = ff_fwd(sv.h3, p.w1, p.b1, p.w2, p.b2, N, residual=xcur, gate=g_f)
+    sv.y = y if ada else None
+    sv.ada = ada
+    sv.has_cross = p.cross and ctx is not None
+    return y, sv
+
+
+def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, dctx_acc=None):
+    """g: fp32 [B*N, D] gradient of the block output.  Returns (dx fp32, dctx fp32|None, dglobal fp32|None,
+    grads dict keyed like BLOCK_PARAM_ORDER)."""
+    D = g.shape[-1]
+    gr = {}
+    ada = sv.ada
+    mod = sv.mod if ada else None
+    sl = (lambda i: mod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
+    dmod = torch.empty_like(mod) if ada else None
+    dsl = (lambda i: dmod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
+    xin_ff = sv.x2 if sv.has_cross else sv.x1
+
+    # ---- feed-forward branch:  y = xin_ff + FF(LN(xin_ff)*(1+sc)+sh) * sigmoid(1-gate)
+    if ada:
+        gb, dg = ops.grad_cast(g, B, N, gate=sl(5), x_out=sv.y, x_in=xin_ff)
+        dsl(5).copy_(dg)
+    else:
+        gb = ops.cast(g, BF16)
+    dh3, gr["ff.ff.0.proj.weight"], gr["ff.ff.0.proj.bias"], gr["ff.ff.2.weight"], gr["ff.ff.2.bias"] = \
+        ff_bwd(gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None)
+    if ada:
+        dsc, dsh = ops.adaln_mod_bwd(dh3, xin_ff, p.g3, p.beta3, sv.mean3, sv.rstd3, B, N)
+        dsl(3).copy_(dsc)
+        dsl(4).copy_(dsh)
+    g2, gr["ff_norm.gamma"], _ = ops.layernorm_bwd(dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3),
+                                                    rows_per_batch=N, dres=g)
+    # ---- cross-attention branch
+    dctx = None
+    if sv.has_cross:
+        g2b = ops.cast(g2, BF16)
+        dh2, dctx, gr["cross_attn.to_q.weight"], gr["cross_attn.to_kv.weight"], gr["cross_attn.to_out.weight"] = \
+            cross_attn_bwd(g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc)
+        g1, gr["cross_attend_norm.gamma"], _ = ops.layernorm_bwd(dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2)
+    else:
+        g1 = g2
+    # ---- self-attention branch:  x1 = x + SA(LN(x)*(1+sc)+sh) * sigmoid(1-gate)   (masked rows contribute 0)
+    if ada:
+        g1b, dg = ops.grad_cast(g1, B, N, gate=sl(2), x_out=sv.x1, x_in=sv.x, row_mask=mask8)
+        dsl(2).copy_(dg)
+    elif mask8 is not None:
+        g1b, _ = ops.grad_cast(g1, B, N, row_mask=mask8)
+    else:
+        g1b = ops.cast(g1, BF16)
+    dh1, gr["self_attn.to_qkv.weight"], gr["self_attn.to_out.weight"] = \
+        self_attn_bwd(g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8)
+    if ada:
+        dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
+        dsl(0).copy_(dsc)
+        dsl(1).copy_(dsh)
+    dx, gr["pre_norm.gamma"], _ = ops.layernorm_bwd(dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0),
+                                                     rows_per_batch=N, dres=g1)
+    dglobal = None
+    if ada:
+        dmb = ops.cast(dmod, BF16)
+        gr["to_scale_shift_gate.1.weight"] = wgrad(dmb, sv.sgb)
+        dsg = dgrad(dmb, p.wmod, out_dtype=F32)
+        dglobal = ops.silu_bwd(dsg, sv.x_global)
+    return dx, dctx, dglobal, gr

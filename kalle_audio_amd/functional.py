@@ -1,0 +1,383 @@
+"""torch.autograd.Function shims over dit_ops / ops: they own forward + backward of each drop-in module, so a
+reference training loop (plain torch autograd, any torch optimizer) runs the hand-written HIP kernels end to end.
+No torch math op computes anything here; torch supplies tensors, streams and the autograd tape only.
+"""
+import torch
+
+from . import dit_ops as D
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _to_bf16(x):
+    return x if x.dtype == BF16 else ops.cast(x.float() if x.dtype not in (F32, BF16) else x, BF16)
+
+
+def _to_f32(x):
+    return x if x.dtype == F32 else ops.cast(x if x.dtype == BF16 else x.to(BF16), F32)
+
+
+def _like(t, dtype):
+    """cast result back to the caller's dtype (fp32 or bf16; fp16 callers get fp32->half via torch plumbing)."""
+    if t.dtype == dtype:
+        return t
+    if dtype == F32:
+        return _to_f32(t)
+    if dtype == BF16:
+        return _to_bf16(t)
+    return _to_f32(t).to(dtype)
+
+
+def _mask8(m):
+    if m is None:
+        return None
+    return m.to(torch.uint8).contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T (+ b) (+ residual); x: [..., K] (bf16 or fp32), W: [N, K] fp32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, out_dtype):
+        shp = x.shape
+        xb = _to_bf16(x.contiguous()).view(-1, shp[-1])
+        wb = D.bf16_of(weight)
+        res = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
+        y = ops.gemm(xb, wb, bias=D.f32_of(bias) if bias is not None else None, residual=res, out_dtype=out_dtype)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.x_dtype = x.dtype
+        ctx.shp = shp
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, weight = ctx.saved_tensors
+        wb = D.bf16_of(weight)
+        dyc = dy.contiguous().view(-1, weight.shape[0])
+        gb = _to_bf16(dyc)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = _like(D.dgrad(gb, wb), ctx.x_dtype).view(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            dw = D.wgrad(gb, xb)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(gb)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres, None
+
+
+def linear(x, weight, bias=None, residual=None, out_dtype=None):
+    if out_dtype is None:
+        out_dtype = F32 if (x.dtype == F32 or residual is not None) else BF16
+    return LinearFn.apply(x, weight, bias, residual, out_dtype)
+
+
+class SiLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.silu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.silu_bwd(_like(dy.contiguous(), x.dtype), x)
+
+
+def silu(x):
+    if x.dtype not in (F32, BF16):
+        x = x.float()
+    return SiLUFn.apply(x)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """transformer.py:173-192"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shp = x.shape
+        xc = x.contiguous().view(-1, shp[-1])
+        if xc.dtype not in (F32, BF16):
+            xc = xc.float()
+        y, mean, rstd = ops.layernorm_fwd(xc, D.f32_of(gamma), D.f32_of(beta) if beta is not None else None, eps=eps)
+        ctx.save_for_backward(xc, gamma, mean, rstd)
+        ctx.has_beta = beta is not None
+        ctx.x_dtype = x.dtype
+        return _like(y, x.dtype).view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gamma, mean, rstd = ctx.saved_tensors
+        dyb = _to_bf16(dy.contiguous().view(-1, xc.shape[-1]))
+        dx, dgamma, dbeta = ops.layernorm_bwd(dyb, xc, D.f32_of(gamma), mean, rstd, want_dbeta=ctx.has_beta)
+        return _like(dx, ctx.x_dtype).view(dy.shape), dgamma, dbeta, None
+
+
+class RMSNormFn(torch.autograd.Function):
+    """blocks.py:268-272"""
+
+    @staticmethod
+    def forward(ctx, x, scale, eps):
+        shp = x.shape
+        xc = x.contiguous().view(-1, shp[-1])
+        if xc.dtype not in (F32, BF16):
+            xc = xc.float()
+        y, rr = ops.rmsnorm_fwd(xc, D.f32_of(scale), eps=eps, out_dtype=xc.dtype)
+        ctx.save_for_backward(xc, scale, rr)
+        return y.view(shp).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, scale, rr = ctx.saved_tensors
+        dyc = dy.contiguous().view(-1, xc.shape[-1])
+        if dyc.dtype not in (F32, BF16):
+            dyc = dyc.float()
+        dx, dscale = ops.rmsnorm_bwd(dyc, xc, D.f32_of(scale), rr)
+        return _like(dx, xc.dtype).view(dy.shape).to(dy.dtype), dscale.view(scale.shape), None
+
+
+class FourierFeaturesFn(torch.autograd.Function):
+    """blocks.py:84-93 (in_features == 1)"""
+
+    @staticmethod
+    def forward(ctx, t, weight):
+        tt = t.contiguous().view(-1).float()
+        w = D.f32_of(weight).contiguous().view(-1)
+        ctx.save_for_backward(tt, w)
+        ctx.wshape = weight.shape
+        return ops.fourier_features(tt, w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        tt, w = ctx.saved_tensors
+        dw = ops.fourier_features_bwd(_to_f32(dout.contiguous()), tt, w)
+        return None, dw.view(ctx.wshape)
+
+
+class TransposeFn(torch.autograd.Function):
+    """(B, R, C) -> (B, C, R) with dtype conversion; optionally dropping the first `skip` rows (dit.py:199,219)."""
+
+    @staticmethod
+    def forward(ctx, x, out_dtype, skip):
+        x = x.contiguous()
+        if x.dtype not in (F32, BF16):
+            x = x.float()
+        B, R, C = x.shape
+        ctx.meta = (x.dtype, B, R, C, skip)
+        src = x[:, skip:] if skip else x
+        return ops.transpose_2d(src, out_dtype=out_dtype, R=R - skip, Cn=C, in_batch_stride=x.stride(0),
+                                in_ld=x.stride(1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dtype, B, R, C, skip = ctx.meta
+        dy = dy.contiguous()
+        if dy.dtype not in (F32, BF16):
+            dy = dy.float()
+        if skip:
+            dx = torch.zeros((B, R, C), device=dy.device, dtype=dtype)
+            ops.transpose_2d(dy, out=dx[:, skip:], out_batch_stride=dx.stride(0), out_ld=dx.stride(1))
+        else:
+            dx = ops.transpose_2d(dy, out_dtype=dtype)
+        return dx, None, None
+
+
+def transpose(x, out_dtype=None, skip=0):
+    return TransposeFn.apply(x, out_dtype or (x.dtype if x.dtype in (F32, BF16) else F32), skip)
+
+
+class SpliceFn(torch.autograd.Function):
+    """residual-stream assembly: out = cat(prepend [B,P,D], tokens [B,T,D]) in fp32 (transformer.py:776-781)."""
+
+    @staticmethod
+    def forward(ctx, prepend, tokens):
+        tokens = tokens.contiguous()
+        B, T, Dm = tokens.shape
+        P = prepend.shape[1] if prepend is not None else 0
+        out = torch.empty((B, P + T, Dm), device=tokens.device, dtype=F32)
+        if P:
+            pre = prepend.contiguous()
+            pre = pre if pre.dtype in (F32, BF16) else pre.float()
+            ops.copy_rows(pre, out, B, P, Dm, pre.stride(0), pre.stride(1), out.stride(0), out.stride(1))
+        tk = tokens if tokens.dtype in (F32, BF16) else tokens.float()
+        ops.copy_rows(tk, out[:, P:], B, T, Dm, tk.stride(0), tk.stride(1), out.stride(0), out.stride(1))
+        ctx.meta = (P, T, prepend.dtype if prepend is not None else None, tokens.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, T, pdt, tdt = ctx.meta
+        g = g.contiguous()
+        B, _, Dm = g.shape
+        dpre = None
+        if P and ctx.needs_input_grad[0]:
+            dpre = torch.empty((B, P, Dm), device=g.device, dtype=F32)
+            ops.copy_rows(g, dpre, B, P, Dm, g.stride(0), g.stride(1), dpre.stride(0), dpre.stride(1))
+            dpre = dpre.to(pdt)
+        odt = tdt if tdt in (F32, BF16) else F32
+        dtok = torch.empty((B, T, Dm), device=g.device, dtype=odt)
+        ops.copy_rows(g[:, P:], dtok, B, T, Dm, g.stride(0), g.stride(1), dtok.stride(0), dtok.stride(1))
+        return dpre, dtok.to(tdt)
+
+
+class TransformerBlockFn(torch.autograd.Function):
+    """One fused TransformerBlock (transformer.py:649-695): LN -> self-attn (+RoPE) -> [LN -> cross-attn] -> LN ->
+    SwiGLU FF with adaLN modulation/gating and residual adds fused into the GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, blk, x, context, global_cond, mask8, cmask8, rope, *params):
+        B, N, Dm = x.shape
+        xin = _to_f32(x.contiguous()).view(B * N, Dm)
+        ctxb = None
+        S = 0
+        if context is not None and blk.cross_attend:
+            S = context.shape[1]
+            ctxb = _to_bf16(context.contiguous()).view(B * S, context.shape[-1])
+        gc = _to_f32(global_cond.contiguous()) if global_cond is not None else None
+        p = D.block_params(blk)
+        y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S)
+        ctx.blk, ctx.sv, ctx.ctxb = blk, sv, ctxb
+        ctx.masks = (mask8, cmask8, rope)
+        ctx.dims = (B, N, S, Dm)
+        ctx.dtypes = (x.dtype, context.dtype if context is not None else None,
+                      global_cond.dtype if global_cond is not None else None)
+        ctx.ctx_shape = context.shape if context is not None else None
+        return _like(y, x.dtype if x.dtype in (F32, BF16) else F32).view(B, N, Dm)
+
+    @staticmethod
+    def backward(ctx, g):
+        blk, sv = ctx.blk, ctx.sv
+        mask8, cmask8, rope = ctx.masks
+        B, N, S, Dm = ctx.dims
+        p = D.block_params(blk)
+        gf = _to_f32(g.contiguous()).view(B * N, Dm)
+        dx, dctx, dglobal, gr = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S)
+        ctx.sv = None
+        xdt, cdt, gdt = ctx.dtypes
+        dx = _like(dx, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
+        if dctx is not None and ctx.needs_input_grad[2]:
+            dctx = dctx.view(ctx.ctx_shape).to(cdt)
+        else:
+            dctx = None
+        if dglobal is not None and ctx.needs_input_grad[3]:
+            dglobal = dglobal.to(gdt)
+        else:
+            dglobal = None
+        names = blk._kalle_param_names
+        pg = tuple(gr.get(n) for n in names)
+        return (None, dx, dctx, dglobal, None, None, None) + pg
+
+
+def transformer_block(blk, x, context=None, global_cond=None, mask=None, context_mask=None, rotary_pos_emb=None):
+    names = getattr(blk, "_kalle_param_names", None)
+    if names is None:
+        have = dict(blk.named_parameters())
+        names = tuple(n for n in D.BLOCK_PARAM_ORDER if n in have)
+        extra = set(have) - set(names)
+        if extra:
+            raise NotImplementedError(f"TransformerBlock options not supported by the HIP path: {sorted(extra)}")
+        blk._kalle_param_names = names
+    have = dict(blk.named_parameters())
+    rope = None
+    if rotary_pos_emb is not None:
+        freqs = rotary_pos_emb[0] if isinstance(rotary_pos_emb, (tuple, list)) else rotary_pos_emb
+        rope = D.rope_tables(freqs[-x.shape[1]:])
+    return TransformerBlockFn.apply(blk, x, context, global_cond, _mask8(mask), _mask8(context_mask), rope,
+                                    *[have[n] for n in names])
+
+
+class AttentionFn(torch.autograd.Function):
+    """Stand-alone Attention module (transformer.py:396-547): projections + fused attention + to_out."""
+
+    @staticmethod
+    def forward(ctx, mod, x, context, mask8, cmask8, rope, *params):
+        B, N, Dm = x.shape
+        H = mod.num_heads
+        h = _to_bf16(x.contiguous()).view(B * N, Dm)
+        cross = hasattr(mod, "to_q")
+        odt = F32 if x.dtype == F32 else BF16
+        if cross:
+            kv_in = context if context is not None else x
+            S = kv_in.shape[1]
+            cb = _to_bf16(kv_in.contiguous()).view(B * S, kv_in.shape[-1])
+            km = cmask8 if context is not None else mask8
+            out, sv = D.cross_attn_fwd(h, cb, D.bf16_of(mod.to_q.weight), D.bf16_of(mod.to_kv.weight),
+                                       D.bf16_of(mod.to_out.weight), B, N, S, H, km, out_dtype=odt, row_mask=mask8)
+            ctx.extra = (cb, S, km, context is not None)
+        else:
+            out, sv = D.self_attn_fwd(h, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight), B, N, H, rope,
+                                      mask8, out_dtype=odt)
+            ctx.extra = None
+        ctx.mod, ctx.h, ctx.sv, ctx.cross = mod, h, sv, cross
+        ctx.meta = (B, N, Dm, H, mask8, rope, x.dtype, context.dtype if context is not None else None,
+                    context.shape if context is not None else None)
+        return out.view(B, N, Dm)
+
+    @staticmethod
+    def backward(ctx, g):
+        mod = ctx.mod
+        B, N, Dm, H, mask8, rope, xdt, cdt, cshape = ctx.meta
+        gf = g.contiguous().view(B * N, Dm)
+        if mask8 is not None:
+            gb, _ = ops.grad_cast(_to_f32(gf), B, N, row_mask=mask8)
+        else:
+            gb = _to_bf16(gf)
+        if ctx.cross:
+            cb, S, km, has_ctx = ctx.extra
+            dh, dctx, dwq, dwkv, dwo = D.cross_attn_bwd(gb, ctx.h, cb, ctx.sv, D.bf16_of(mod.to_q.weight),
+                                                        D.bf16_of(mod.to_kv.weight), D.bf16_of(mod.to_out.weight),
+                                                        B, N, S, H, km)
+            dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
+            dc = None
+            if has_ctx:
+                dc = dctx.view(cshape).to(cdt)
+            else:
+                dx = dx + dctx.view(B, N, Dm).to(dx.dtype)  # kv_input == x: tape-level add of two input gradients
+            return (None, dx, dc, None, None, None, dwq, dwkv, dwo)
+        dh, dwqkv, dwo = D.self_attn_bwd(gb, ctx.h, ctx.sv, D.bf16_of(mod.to_qkv.weight),
+                                         D.bf16_of(mod.to_out.weight), B, N, H, rope, mask8)
+        dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
+        return (None, dx, None, None, None, None, dwqkv, dwo)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """Stand-alone FeedForward (transformer.py:221-269), SwiGLU variant."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w1, b1, w2, b2):
+        shp = x.shape
+        h = _to_bf16(x.contiguous()).view(-1, shp[-1])
+        odt = F32 if x.dtype == F32 else BF16
+        out, sv = D.ff_fwd(h, D.bf16_of(w1), D.f32_of(b1) if b1 is not None else None, D.bf16_of(w2),
+                           D.f32_of(b2) if b2 is not None else None, 1, out_dtype=odt)
+        ctx.h, ctx.sv, ctx.ws, ctx.meta = h, sv, (w1, w2), (shp, x.dtype, b1 is not None)
+        return out.view(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        shp, xdt, has_bias = ctx.meta
+        w1, w2 = ctx.ws
+        gb = _to_bf16(g.contiguous().view(-1, w2.shape[0]))
+        dh, dw1, db1, dw2, db2 = D.ff_bwd(gb, ctx.h, ctx.sv, D.bf16_of(w1), D.bf16_of(w2), want_bias=has_bias)
+        return None, _like(dh, xdt if xdt in (F32, BF16) else F32).view(shp), dw1, db1, dw2, db2
+
+
+class MSELossFn(torch.autograd.Function):
+    """training/losses/losses.py:53-69"""
+
+    @staticmethod
+    def forward(ctx, output, target, mask, weight):
+        loss, diff = ops.mse_loss(_to_f32(output), _to_f32(target), mask, weight=weight, want_grad=True)
+        ctx.save_for_backward(diff)
+        ctx.odt = output.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (diff,) = ctx.saved_tensors
+        return (diff * gl).to(ctx.odt), None, None, None

@@ -41,7 +41,7 @@ def _rows2d(t):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bfloat16, M=None, N=None, K=None,
          lda=None, ldb=None, ldc=None, bias=None, gate=None, rows_per_batch=0, residual=None, accumulate=False,
-         alpha=1.0, c_rows_per_batch=0, c_batch_rows=0, c_row_offset=0):
+         alpha=1.0, c_rows_per_batch=0, c_batch_rows=0, c_row_offset=0, row_mask=None):
     """C = op(a) @ op(b) with the fused epilogue of kalle_gemm_bf16.
 
     a: [M,K] (or [K,M] when a_kmajor), b: [N,K] (or [K,N] when b_kmajor); both bf16, last dim contiguous.
@@ -72,6 +72,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     ep.accumulate = 1 if accumulate else 0
     ep.alpha = alpha
     ep.c_rows_per_batch, ep.c_batch_rows, ep.c_row_offset = c_rows_per_batch, c_batch_rows, c_row_offset
+    ep.row_mask = row_mask.data_ptr() if row_mask is not None else None
     if bias is not None:
         assert bias.dtype == torch.float32
     if gate is not None:
@@ -261,6 +262,29 @@ def fourier_features(t, w, out_dtype=torch.float32):
     check(lib.kalle_fourier_features(_p(t.contiguous()), _p(w.contiguous()), _p(out), _dt(out), B, half, _stream()),
           "kalle_fourier_features")
     return out
+
+
+def fourier_features_bwd(dout, t, w):
+    lib = _lib.load()
+    dw = torch.empty_like(w)
+    check(lib.kalle_fourier_features_bwd(_p(dout.contiguous()), _p(t.contiguous()), _p(w.contiguous()), _p(dw),
+                                         t.shape[0], w.shape[0], _stream()), "kalle_fourier_features_bwd")
+    return dw
+
+
+def grad_cast(g, nbatch, rows_per_batch, gate=None, x_out=None, x_in=None, row_mask=None):
+    """fp32 residual-stream gradient -> bf16 GEMM operand (+ adaLN gate backward). Returns (gb, dgate or None)."""
+    lib = _lib.load()
+    D = g.shape[-1]
+    g = g.contiguous()
+    gb = torch.empty(g.shape, device=g.device, dtype=torch.bfloat16)
+    if gate is not None:
+        gate = gate.contiguous()  # [B, D] slice of the adaLN modulation; dgate shares its leading dim
+    dgate = torch.empty_like(gate) if gate is not None else None
+    check(lib.kalle_grad_cast(_p(g), _p(x_out), _p(x_in), _p(gate), gate.stride(-2) if gate is not None else 0,
+                              _p(row_mask), _p(gb), _p(dgate), nbatch, rows_per_batch, D, _stream()),
+          "kalle_grad_cast")
+    return gb, dgate
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, param_bf16, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,

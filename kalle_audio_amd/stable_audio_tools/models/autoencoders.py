@@ -1,0 +1,410 @@
+"""Drop-in for the Oobleck VAE of stable_audio_tools/models/autoencoders.py: WNConv1d / WNConvTranspose1d (the
+dac.nn.layers wrappers, line 9), get_activation (24-37), ResidualUnit (39-62), EncoderBlock (64-81), DecoderBlock
+(83-114), OobleckEncoder (116-147), OobleckDecoder (150-191), AudioAutoencoder (230-560, encode/decode and the
+chunked overlap-and-paste variants), create_{encoder,decoder,autoencoder}_from_config (611-731).
+State-dict keys match torch's old-style weight_norm (`weight_g`, `weight_v`, `bias`) and SnakeBeta (`alpha`, `beta`),
+i.e. Stable-Audio-Open checkpoints load unchanged.  Forward only (the VAE is frozen in every reference script,
+factory.py:77-80); all math runs in kalle_audio_amd/csrc/conv1d.hip.  DAC / SEANet / local-attention / diffusion
+autoencoders of the same file are other model families and are not built.
+"""
+import math
+from typing import Any, Dict, Literal
+
+import torch
+from torch import nn
+
+from ... import conv_ops
+from .blocks import SnakeBeta
+from .bottleneck import Bottleneck
+
+
+def _prep(x):
+    if not x.is_cuda:
+        raise RuntimeError("kalle_audio_amd VAE modules run on an MI355X GPU only (no CPU fallback)")
+    return x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
+
+
+def _act_args(act):
+    """(code, alpha, beta, logscale) for the conv kernels' fused input activation."""
+    if act is None or isinstance(act, nn.Identity):
+        return 0, None, None, True
+    if isinstance(act, SnakeBeta):
+        return 1, act.alpha.detach().float(), act.beta.detach().float(), act.alpha_logscale
+    if isinstance(act, nn.ELU):
+        return 2, None, None, True
+    raise NotImplementedError(f"activation {type(act).__name__}")
+
+
+class _WNBase(nn.Module):
+    transposed = False
+
+    def _packed(self):
+        key = (self.weight_g._version, self.weight_v._version, self.weight_v.device)
+        c = getattr(self, "_kalle_packed", None)
+        if c is None or c[0] != key:
+            c = (key, conv_ops.weight_norm_fold(self.weight_v, self.weight_g, transposed=self.transposed))
+            self._kalle_packed = c
+        return c[1]
+
+    def _bias(self):
+        return self.bias.detach().float() if self.bias is not None else None
+
+
+class WNConv1d(_WNBase):
+    """weight_norm(nn.Conv1d) (dac.nn.layers.WNConv1d): parameters weight_g [Cout,1,1], weight_v [Cout,Cin,K], bias."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        ref = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride,
+                        padding=0 if isinstance(padding, str) else padding, dilation=dilation, bias=bias)
+        if padding == 'same':
+            # PyTorch 'same': total = dilation*(k-1), left = total//2 ; symmetric only for odd k (asymmetric not built)
+            if (dilation * (kernel_size - 1)) % 2:
+                raise NotImplementedError("padding='same' with an even kernel (use_nearest_upsample path)")
+            padding = dilation * (kernel_size - 1) // 2
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.weight_v = nn.Parameter(ref.weight.detach().clone())
+        self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+
+    def forward(self, x, act=None, residual=None, post=0):
+        x = _prep(x)
+        code, a, b, ls = _act_args(act)
+        return conv_ops.conv1d(x, self._packed(), self._bias(), Cout=self.out_channels, K=self.kernel_size,
+                               stride=self.stride, padding=self.padding, dilation=self.dilation, act=code, alpha=a,
+                               beta=b, logscale=ls, residual=residual, post=post)
+
+
+class WNConvTranspose1d(_WNBase):
+    """weight_norm(nn.ConvTranspose1d): weight_g [Cin,1,1], weight_v [Cin,Cout,K], bias [Cout]."""
+    transposed = True
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        ref = nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding = stride, padding
+        self.weight_v = nn.Parameter(ref.weight.detach().clone())
+        self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+
+    def forward(self, x, act=None):
+        x = _prep(x)
+        code, a, b, ls = _act_args(act)
+        return conv_ops.conv_transpose1d(x, self._packed(), self._bias(), Cout=self.out_channels,
+                                         K=self.kernel_size, stride=self.stride, padding=self.padding, act=code,
+                                         alpha=a, beta=b, logscale=ls)
+
+
+def get_activation(activation: Literal["elu", "snake", "none"], antialias=False, channels=None) -> nn.Module:
+    """autoencoders.py:24-37"""
+    if antialias:
+        raise NotImplementedError("antialias_activation wraps the third-party alias_free_torch.Activation1d "
+                                  "(not in the reference tree)")
+    if activation == "elu":
+        return nn.ELU()
+    if activation == "snake":
+        return SnakeBeta(channels)
+    if activation == "none":
+        return nn.Identity()
+    raise ValueError(f"Unknown activation {activation}")
+
+
+class ResidualUnit(nn.Module):
+    """autoencoders.py:39-62: x + conv1(act(conv7_dilated(act(x)))); activations and the residual add are fused
+    into the two conv kernels."""
+
+    def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
+        super().__init__()
+        self.dilation = dilation
+        padding = (dilation * (7 - 1)) // 2
+        self.layers = nn.Sequential(
+            get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=out_channels),
+            WNConv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=7, dilation=dilation,
+                     padding=padding),
+            get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=out_channels),
+            WNConv1d(in_channels=out_channels, out_channels=out_channels, kernel_size=1))
+
+    def forward(self, x):
+        x = _prep(x)
+        h = self.layers[1](x, act=self.layers[0])
+        return self.layers[3](h, act=self.layers[2], residual=x)
+
+
+class EncoderBlock(nn.Module):
+    """autoencoders.py:64-81"""
+
+    def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False):
+        super().__init__()
+        self.layers = nn.Sequential(
+            ResidualUnit(in_channels=in_channels, out_channels=in_channels, dilation=1, use_snake=use_snake),
+            ResidualUnit(in_channels=in_channels, out_channels=in_channels, dilation=3, use_snake=use_snake),
+            ResidualUnit(in_channels=in_channels, out_channels=in_channels, dilation=9, use_snake=use_snake),
+            get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=in_channels),
+            WNConv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=2 * stride, stride=stride,
+                     padding=math.ceil(stride / 2)))
+
+    def forward(self, x):
+        for i in range(3):
+            x = self.layers[i](x)
+        return self.layers[4](x, act=self.layers[3])
+
+
+class DecoderBlock(nn.Module):
+    """autoencoders.py:83-114"""
+
+    def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False,
+                 use_nearest_upsample=False):
+        super().__init__()
+        if use_nearest_upsample:
+            raise NotImplementedError("use_nearest_upsample (nn.Upsample + even-kernel 'same' conv) is not built")
+        upsample_layer = WNConvTranspose1d(in_channels=in_channels, out_channels=out_channels,
+                                           kernel_size=2 * stride + stride % 2, stride=stride,
+                                           padding=math.ceil(stride / 2))
+        self.layers = nn.Sequential(
+            get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=in_channels),
+            upsample_layer,
+            ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=1, use_snake=use_snake),
+            ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=3, use_snake=use_snake),
+            ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=9, use_snake=use_snake))
+
+    def forward(self, x):
+        x = self.layers[1](x, act=self.layers[0])
+        for i in range(2, 5):
+            x = self.layers[i](x)
+        return x
+
+
+class OobleckEncoder(nn.Module):
+    """autoencoders.py:116-147"""
+
+    def __init__(self, in_channels=2, channels=128, latent_dim=32, c_mults=[1, 2, 4, 8], strides=[2, 4, 8, 8],
+                 use_snake=False, antialias_activation=False):
+        super().__init__()
+        c_mults = [1] + c_mults
+        self.depth = len(c_mults)
+        layers = [WNConv1d(in_channels=in_channels, out_channels=c_mults[0] * channels, kernel_size=7, padding=3)]
+        for i in range(self.depth - 1):
+            layers += [EncoderBlock(in_channels=c_mults[i] * channels, out_channels=c_mults[i + 1] * channels,
+                                    stride=strides[i], use_snake=use_snake)]
+        layers += [get_activation("snake" if use_snake else "elu", antialias=antialias_activation,
+                                  channels=c_mults[-1] * channels),
+                   WNConv1d(in_channels=c_mults[-1] * channels, out_channels=latent_dim, kernel_size=3, padding=1)]
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, x):
+        n = len(self.layers)
+        x = self.layers[0](x)
+        for i in range(1, n - 2):
+            x = self.layers[i](x)
+        return self.layers[n - 1](x, act=self.layers[n - 2])
+
+
+class OobleckDecoder(nn.Module):
+    """autoencoders.py:150-191"""
+
+    def __init__(self, out_channels=2, channels=128, latent_dim=32, c_mults=[1, 2, 4, 8], strides=[2, 4, 8, 8],
+                 use_snake=False, antialias_activation=False, use_nearest_upsample=False, final_tanh=True):
+        super().__init__()
+        c_mults = [1] + c_mults
+        self.depth = len(c_mults)
+        layers = [WNConv1d(in_channels=latent_dim, out_channels=c_mults[-1] * channels, kernel_size=7, padding=3)]
+        for i in range(self.depth - 1, 0, -1):
+            layers += [DecoderBlock(in_channels=c_mults[i] * channels, out_channels=c_mults[i - 1] * channels,
+                                    stride=strides[i - 1], use_snake=use_snake,
+                                    antialias_activation=antialias_activation,
+                                    use_nearest_upsample=use_nearest_upsample)]
+        layers += [get_activation("snake" if use_snake else "elu", antialias=antialias_activation,
+                                  channels=c_mults[0] * channels),
+                   WNConv1d(in_channels=c_mults[0] * channels, out_channels=out_channels, kernel_size=7, padding=3,
+                            bias=False),
+                   nn.Tanh() if final_tanh else nn.Identity()]
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, x):
+        n = len(self.layers)
+        x = self.layers[0](x)
+        for i in range(1, n - 3):
+            x = self.layers[i](x)
+        post = 1 if isinstance(self.layers[n - 1], nn.Tanh) else 0
+        return self.layers[n - 2](x, act=self.layers[n - 3], post=post)   # tanh fused into the store
+
+
+class AudioAutoencoder(nn.Module):
+    """autoencoders.py:230-560 (encode / decode / chunked encode_audio / decode_audio)."""
+
+    def __init__(self, encoder, decoder, latent_dim, downsampling_ratio, sample_rate, io_channels=2,
+                 bottleneck: Bottleneck = None, pretransform=None, in_channels=None, out_channels=None,
+                 soft_clip=False):
+        super().__init__()
+        self.downsampling_ratio = downsampling_ratio
+        self.sample_rate = sample_rate
+        self.latent_dim = latent_dim
+        self.io_channels = io_channels
+        self.in_channels = io_channels if in_channels is None else in_channels
+        self.out_channels = io_channels if out_channels is None else out_channels
+        self.min_length = self.downsampling_ratio
+        self.bottleneck = bottleneck
+        self.encoder = encoder
+        self.decoder = decoder
+        if pretransform is not None:
+            raise NotImplementedError("nested pretransforms inside the autoencoder")
+        self.pretransform = None
+        self.soft_clip = soft_clip
+        self.is_discrete = self.bottleneck is not None and self.bottleneck.is_discrete
+
+    def encode(self, audio, return_info=False, skip_pretransform=False, iterate_batch=False, **kwargs):
+        info = {}
+        if self.encoder is not None:
+            if iterate_batch:
+                latents = torch.cat([self.encoder(audio[i:i + 1]) for i in range(audio.shape[0])], dim=0)
+            else:
+                latents = self.encoder(audio)
+        else:
+            latents = audio
+        if self.bottleneck is not None:
+            latents, bottleneck_info = self.bottleneck.encode(latents, return_info=True, **kwargs)
+            info.update(bottleneck_info)
+        if return_info:
+            return latents, info
+        return latents
+
+    def decode(self, latents, iterate_batch=False, **kwargs):
+        if self.bottleneck is not None:
+            latents = self.bottleneck.decode(latents)
+        if iterate_batch:
+            decoded = torch.cat([self.decoder(latents[i:i + 1]) for i in range(latents.shape[0])], dim=0)
+        else:
+            decoded = self.decoder(latents, **kwargs)
+        if self.soft_clip:
+            decoded = torch.tanh(decoded)
+        return decoded
+
+    @staticmethod
+    def _chunks(x, chunk_size, hop_size):
+        total = x.shape[2]
+        starts = list(range(0, total - chunk_size + 1, hop_size))
+        chunks = [x[:, :, i:i + chunk_size] for i in starts]
+        if not starts or starts[-1] + chunk_size != total:
+            chunks.append(x[:, :, -chunk_size:])
+        return chunks
+
+    def encode_audio(self, audio, chunked=False, overlap=32, chunk_size=128, **kwargs):
+        """autoencoders.py:429-497: overlap-and-paste over chunks measured in latents."""
+        if not chunked:
+            return self.encode(audio, **kwargs)
+        spl = self.downsampling_ratio
+        total_size, batch_size = audio.shape[2], audio.shape[0]
+        chunk_size *= spl
+        overlap *= spl
+        hop_size = chunk_size - overlap
+        chunks = self._chunks(audio, chunk_size, hop_size)
+        num_chunks = len(chunks)
+        y_size = total_size // spl
+        y_final = None
+        for i in range(num_chunks):
+            y_chunk = self.encode(chunks[i])
+            if y_final is None:
+                y_final = torch.zeros((batch_size, y_chunk.shape[1], y_size), device=audio.device, dtype=y_chunk.dtype)
+            if i == num_chunks - 1:
+                t_end = y_size
+                t_start = t_end - y_chunk.shape[2]
+            else:
+                t_start = i * hop_size // spl
+                t_end = t_start + chunk_size // spl
+            ol = overlap // spl // 2
+            chunk_start, chunk_end = 0, y_chunk.shape[2]
+            if i > 0:
+                t_start += ol
+                chunk_start += ol
+            if i < num_chunks - 1:
+                t_end -= ol
+                chunk_end -= ol
+            y_final[:, :, t_start:t_end] = y_chunk[:, :, chunk_start:chunk_end]
+        return y_final
+
+    def decode_audio(self, latents, chunked=False, overlap=32, chunk_size=128, **kwargs):
+        """autoencoders.py:499-560"""
+        if not chunked:
+            return self.decode(latents, **kwargs)
+        hop_size = chunk_size - overlap
+        total_size, batch_size = latents.shape[2], latents.shape[0]
+        chunks = self._chunks(latents, chunk_size, hop_size)
+        num_chunks = len(chunks)
+        spl = self.downsampling_ratio
+        y_size = total_size * spl
+        y_final = None
+        for i in range(num_chunks):
+            y_chunk = self.decode(chunks[i].contiguous())
+            if y_final is None:
+                y_final = torch.zeros((batch_size, self.out_channels, y_size), device=latents.device,
+                                      dtype=y_chunk.dtype)
+            if i == num_chunks - 1:
+                t_end = y_size
+                t_start = t_end - y_chunk.shape[2]
+            else:
+                t_start = i * hop_size * spl
+                t_end = t_start + chunk_size * spl
+            ol = (overlap // 2) * spl
+            chunk_start, chunk_end = 0, y_chunk.shape[2]
+            if i > 0:
+                t_start += ol
+                chunk_start += ol
+            if i < num_chunks - 1:
+                t_end -= ol
+                chunk_end -= ol
+            y_final[:, :, t_start:t_end] = y_chunk[:, :, chunk_start:chunk_end]
+        return y_final
+
+
+def create_encoder_from_config(encoder_config: Dict[str, Any]):
+    """autoencoders.py:611-650 (oobleck only)"""
+    encoder_type = encoder_config.get("type", None)
+    assert encoder_type is not None, "Encoder type must be specified"
+    if encoder_type != "oobleck":
+        raise NotImplementedError(f"encoder type {encoder_type!r}: only 'oobleck' is on the accelerated path")
+    encoder = OobleckEncoder(**encoder_config["config"])
+    if not encoder_config.get("requires_grad", True):
+        for param in encoder.parameters():
+            param.requires_grad = False
+    return encoder
+
+
+def create_decoder_from_config(decoder_config: Dict[str, Any]):
+    """autoencoders.py:652-685 (oobleck only)"""
+    decoder_type = decoder_config.get("type", None)
+    assert decoder_type is not None, "Decoder type must be specified"
+    if decoder_type != "oobleck":
+        raise NotImplementedError(f"decoder type {decoder_type!r}: only 'oobleck' is on the accelerated path")
+    decoder = OobleckDecoder(**decoder_config["config"])
+    if not decoder_config.get("requires_grad", True):
+        for param in decoder.parameters():
+            param.requires_grad = False
+    return decoder
+
+
+def create_autoencoder_from_config(config: Dict[str, Any]):
+    """autoencoders.py:687-731"""
+    from .factory import create_bottleneck_from_config
+    ae_config = config["model"]
+    encoder = create_encoder_from_config(ae_config["encoder"])
+    decoder = create_decoder_from_config(ae_config["decoder"])
+    bottleneck = ae_config.get("bottleneck", None)
+    latent_dim = ae_config.get("latent_dim", None)
+    assert latent_dim is not None, "latent_dim must be specified in model config"
+    downsampling_ratio = ae_config.get("downsampling_ratio", None)
+    assert downsampling_ratio is not None, "downsampling_ratio must be specified in model config"
+    io_channels = ae_config.get("io_channels", None)
+    assert io_channels is not None, "io_channels must be specified in model config"
+    sample_rate = config.get("sample_rate", None)
+    assert sample_rate is not None, "sample_rate must be specified in model config"
+    if ae_config.get("pretransform", None) is not None:
+        raise NotImplementedError("nested pretransforms inside the autoencoder")
+    if bottleneck is not None:
+        bottleneck = create_bottleneck_from_config(bottleneck)
+    return AudioAutoencoder(encoder, decoder, io_channels=io_channels, latent_dim=latent_dim,
+                            downsampling_ratio=downsampling_ratio, sample_rate=sample_rate, bottleneck=bottleneck,
+                            in_channels=ae_config.get("in_channels", None),
+                            out_channels=ae_config.get("out_channels", None),
+                            soft_clip=ae_config["decoder"].get("soft_clip", False))

@@ -1,0 +1,241 @@
+"""Drop-in for stable_audio_tools/models/transformer.py (reference file:line cited per class): same class names,
+constructor kwargs, forward signatures and state-dict keys; every forward runs the hand-written gfx950 kernels
+(kalle_audio_amd/csrc) through autograd shims.  GPU tensors only - there is no CPU or torch-math fallback.
+
+Not carried over (raise NotImplementedError when requested): causal attention, qk_norm, natten neighbourhood
+attention, conv feed-forward, ConformerModule, sinusoidal/absolute position embeddings - none is reachable from
+the DiT path (dit.py:107-125) with the configs the reference ships.
+"""
+import torch
+from torch import nn
+
+from ... import functional as KF
+
+
+def _need_gpu(x):
+    if not x.is_cuda:
+        raise RuntimeError("kalle_audio_amd modules run on an MI355X GPU only (hand-written HIP kernels, no CPU "
+                           "fallback); move the module and its inputs to cuda")
+
+
+class RotaryEmbedding(nn.Module):
+    """transformer.py:89-144 (use_xpos=False path; `inv_freq` is a persistent buffer, line 106)."""
+
+    def __init__(self, dim, use_xpos=False, scale_base=512, interpolation_factor=1., base=10000,
+                 base_rescale_factor=1.):
+        super().__init__()
+        if use_xpos:
+            raise NotImplementedError("use_xpos (unreachable in the reference: transformer.py:140 uses an undefined name)")
+        base *= base_rescale_factor ** (dim / (dim - 2))
+        self.register_buffer("inv_freq", 1. / (base ** (torch.arange(0, dim, 2).float() / dim)))
+        assert interpolation_factor >= 1.
+        self.interpolation_factor = interpolation_factor
+        self.register_buffer("scale", None)
+
+    def forward_from_seq_len(self, seq_len):
+        return self.forward(torch.arange(seq_len, device=self.inv_freq.device))
+
+    def forward(self, t):
+        # position table set-up (N x rot/2 values), not data-path math
+        t = t.to(torch.float32) / self.interpolation_factor
+        freqs = t[:, None] * self.inv_freq[None, :].float()
+        return torch.cat((freqs, freqs), dim=-1), 1.
+
+
+class LayerNorm(nn.Module):
+    """transformer.py:173-192: bias-less LayerNorm; gamma Parameter, beta zero buffer unless bias=True."""
+
+    def __init__(self, dim, bias=False, fix_scale=False):
+        super().__init__()
+        if fix_scale:
+            self.register_buffer("gamma", torch.ones(dim))
+        else:
+            self.gamma = nn.Parameter(torch.ones(dim))
+        if bias:
+            self.beta = nn.Parameter(torch.zeros(dim))
+        else:
+            self.register_buffer("beta", torch.zeros(dim))
+
+    def forward(self, x):
+        _need_gpu(x)
+        beta = self.beta if isinstance(self.beta, nn.Parameter) else None
+        return KF.LayerNormFn.apply(x, self.gamma, beta, 1e-5)
+
+
+class GLU(nn.Module):
+    """transformer.py:196-219 (parameter container; the fused FeedForward kernel path does the math)."""
+
+    def __init__(self, dim_in, dim_out, activation, use_conv=False, conv_kernel_size=3):
+        super().__init__()
+        if use_conv:
+            raise NotImplementedError("GLU(use_conv=True)")
+        if not isinstance(activation, nn.SiLU):
+            raise NotImplementedError("only the SwiGLU activation the reference uses (transformer.py:238)")
+        self.act = activation
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+        self.use_conv = use_conv
+
+
+class FeedForward(nn.Module):
+    """transformer.py:221-269: SwiGLU feed-forward, zero-initialised output projection (255-258)."""
+
+    def __init__(self, dim, dim_out=None, mult=4, no_bias=False, glu=True, use_conv=False, conv_kernel_size=3,
+                 zero_init_output=True):
+        super().__init__()
+        if not glu or use_conv:
+            raise NotImplementedError("FeedForward(glu=False / use_conv=True)")
+        inner_dim = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        linear_in = GLU(dim, inner_dim, nn.SiLU())
+        if no_bias:
+            linear_in.proj = nn.Linear(dim, inner_dim * 2)  # the reference GLU always has a bias (207)
+        linear_out = nn.Linear(inner_dim, dim_out, bias=not no_bias)
+        if zero_init_output:
+            nn.init.zeros_(linear_out.weight)
+            if not no_bias:
+                nn.init.zeros_(linear_out.bias)
+        self.ff = nn.Sequential(linear_in, nn.Identity(), linear_out, nn.Identity())
+
+    def forward(self, x):
+        _need_gpu(x)
+        l1, l2 = self.ff[0].proj, self.ff[2]
+        return KF.FeedForwardFn.apply(self, x, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
+class Attention(nn.Module):
+    """transformer.py:271-547."""
+
+    def __init__(self, dim, dim_heads=64, dim_context=None, causal=False, zero_init_output=True, qk_norm='none',
+                 natten_kernel_size=None):
+        super().__init__()
+        if causal or qk_norm != 'none' or natten_kernel_size is not None:
+            raise NotImplementedError("Attention(causal / qk_norm / natten): not on the DiT path (dit.py:252)")
+        if dim_heads != 64:
+            raise NotImplementedError("the fused attention kernel is specialised for head dim 64")
+        self.dim = dim
+        self.dim_heads = dim_heads
+        self.causal = causal
+        dim_kv = dim_context if dim_context is not None else dim
+        self.num_heads = dim // dim_heads
+        self.kv_heads = dim_kv // dim_heads
+        if dim_context is not None:
+            self.to_q = nn.Linear(dim, dim, bias=False)
+            self.to_kv = nn.Linear(dim_kv, dim_kv * 2, bias=False)
+        else:
+            self.to_qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.to_out = nn.Linear(dim, dim, bias=False)
+        if zero_init_output:
+            nn.init.zeros_(self.to_out.weight)
+        self.qk_norm = qk_norm
+        self.natten_kernel_size = natten_kernel_size
+
+    def forward(self, x, context=None, mask=None, context_mask=None, rotary_pos_emb=None, causal=None):
+        _need_gpu(x)
+        if causal:
+            raise NotImplementedError("causal attention")
+        rope = None
+        if rotary_pos_emb is not None and context is None:
+            freqs = rotary_pos_emb[0] if isinstance(rotary_pos_emb, (tuple, list)) else rotary_pos_emb
+            rope = KF.D.rope_tables(freqs[-x.shape[1]:])
+        if hasattr(self, "to_q"):
+            params = (self.to_q.weight, self.to_kv.weight, self.to_out.weight)
+        else:
+            params = (self.to_qkv.weight, self.to_out.weight)
+        return KF.AttentionFn.apply(self, x, context, KF._mask8(mask), KF._mask8(context_mask), rope, *params)
+
+
+class TransformerBlock(nn.Module):
+    """transformer.py:585-695."""
+
+    def __init__(self, dim, dim_heads=64, cross_attend=False, dim_context=None, global_cond_dim=None, causal=False,
+                 zero_init_branch_outputs=True, conformer=False, layer_ix=-1, remove_norms=False, attn_kwargs={},
+                 ff_kwargs={}, norm_kwargs={}):
+        super().__init__()
+        if conformer or remove_norms or causal:
+            raise NotImplementedError("TransformerBlock(conformer / remove_norms / causal)")
+        self.dim = dim
+        self.dim_heads = dim_heads
+        self.cross_attend = cross_attend
+        self.dim_context = dim_context
+        self.causal = causal
+        self.pre_norm = LayerNorm(dim, **norm_kwargs)
+        self.self_attn = Attention(dim, dim_heads=dim_heads, causal=causal,
+                                   zero_init_output=zero_init_branch_outputs, **attn_kwargs)
+        if cross_attend:
+            self.cross_attend_norm = LayerNorm(dim, **norm_kwargs)
+            self.cross_attn = Attention(dim, dim_heads=dim_heads, dim_context=dim_context, causal=causal,
+                                        zero_init_output=zero_init_branch_outputs, **attn_kwargs)
+        self.ff_norm = LayerNorm(dim, **norm_kwargs)
+        self.ff = FeedForward(dim, zero_init_output=zero_init_branch_outputs, **ff_kwargs)
+        self.layer_ix = layer_ix
+        self.conformer = None
+        self.global_cond_dim = global_cond_dim
+        if global_cond_dim is not None:
+            self.to_scale_shift_gate = nn.Sequential(nn.SiLU(), nn.Linear(global_cond_dim, dim * 6, bias=False))
+            nn.init.zeros_(self.to_scale_shift_gate[1].weight)
+
+    def forward(self, x, context=None, global_cond=None, mask=None, context_mask=None, rotary_pos_emb=None):
+        _need_gpu(x)
+        if isinstance(self.pre_norm.beta, nn.Parameter):
+            raise NotImplementedError("LayerNorm(bias=True) inside the fused block")
+        return KF.transformer_block(self, x, context=context, global_cond=global_cond, mask=mask,
+                                    context_mask=context_mask, rotary_pos_emb=rotary_pos_emb)
+
+
+class ContinuousTransformer(nn.Module):
+    """transformer.py:697-812.  The reference wraps every layer in torch.utils.checkpoint (802, recompute in
+    backward); with 288 GB of HBM3E per MI355X the block kernels keep their activations instead."""
+
+    def __init__(self, dim, depth, *, dim_in=None, dim_out=None, dim_heads=64, cross_attend=False,
+                 cond_token_dim=None, global_cond_dim=None, causal=False, rotary_pos_emb=True,
+                 zero_init_branch_outputs=True, conformer=False, use_sinusoidal_emb=False, use_abs_pos_emb=False,
+                 abs_pos_emb_max_length=10000, **kwargs):
+        super().__init__()
+        if use_sinusoidal_emb or use_abs_pos_emb or conformer or causal:
+            raise NotImplementedError("ContinuousTransformer(sinusoidal/abs pos emb, conformer, causal)")
+        self.dim = dim
+        self.depth = depth
+        self.causal = causal
+        self.layers = nn.ModuleList([])
+        self.project_in = nn.Linear(dim_in, dim, bias=False) if dim_in is not None else nn.Identity()
+        self.project_out = nn.Linear(dim, dim_out, bias=False) if dim_out is not None else nn.Identity()
+        self.rotary_pos_emb = RotaryEmbedding(max(dim_heads // 2, 32)) if rotary_pos_emb else None
+        self.use_sinusoidal_emb = use_sinusoidal_emb
+        self.use_abs_pos_emb = use_abs_pos_emb
+        for i in range(depth):
+            self.layers.append(TransformerBlock(dim, dim_heads=dim_heads, cross_attend=cross_attend,
+                                                dim_context=cond_token_dim, global_cond_dim=global_cond_dim,
+                                                causal=causal, zero_init_branch_outputs=zero_init_branch_outputs,
+                                                conformer=conformer, layer_ix=i, **kwargs))
+
+    def forward(self, x, mask=None, prepend_embeds=None, prepend_mask=None, global_cond=None, return_info=False,
+                **kwargs):
+        _need_gpu(x)
+        batch, seq, device = *x.shape[:2], x.device
+        info = {"hidden_states": []}
+        if isinstance(self.project_in, nn.Linear):
+            x = KF.linear(x, self.project_in.weight, out_dtype=torch.bfloat16)
+        if prepend_embeds is not None:
+            prepend_length, prepend_dim = prepend_embeds.shape[1:]
+            assert prepend_dim == x.shape[-1], 'prepend dimension must match sequence dimension'
+            x = KF.SpliceFn.apply(prepend_embeds, x)
+            if prepend_mask is not None or mask is not None:
+                mask = mask if mask is not None else torch.ones((batch, seq), device=device, dtype=torch.bool)
+                prepend_mask = prepend_mask if prepend_mask is not None else torch.ones(
+                    (batch, prepend_length), device=device, dtype=torch.bool)
+                mask = torch.cat((prepend_mask, mask), dim=-1)
+        else:
+            x = KF.SpliceFn.apply(None, x)
+        rotary = self.rotary_pos_emb.forward_from_seq_len(x.shape[1]) if self.rotary_pos_emb is not None else None
+        # an all-true mask is the common case (dit.py:189): skip the masked kernels' extra work
+        if mask is not None and bool(mask.all()):
+            mask = None
+        for layer in self.layers:
+            x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
+            if return_info:
+                info["hidden_states"].append(x)
+        if isinstance(self.project_out, nn.Linear):
+            x = KF.linear(x, self.project_out.weight, out_dtype=torch.float32)
+        if return_info:
+            return x, info
+        return x

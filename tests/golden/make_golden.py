@@ -263,6 +263,19 @@ def main():
             z = pt.encode(wav)              # mean || scale (bottleneck is a pass-through in this reference)
             rec = pt.decode(z[:, :4])
         save(f"oobleck_vae_{tag}", z=z, rec=rec)
+    # ---- state-dict key/shape inventories (the drop-in contract) ---------------------------------
+    import json
+    inv = {}
+    for gtype in ("prepend", "adaLN"):
+        dit = DiffusionTransformer(io_channels=CIO, embed_dim=D, depth=2, num_heads=2, cond_token_dim=DC,
+                                   project_cond_tokens=True, global_cond_dim=G, prepend_cond_dim=24,
+                                   transformer_type="continuous_transformer", global_cond_type=gtype)
+        inv[f"dit_{gtype}"] = {k: list(v.shape) for k, v in dit.state_dict().items()}
+    cfg["model"]["encoder"]["config"]["use_snake"] = True
+    cfg["model"]["decoder"]["config"]["use_snake"] = True
+    inv["oobleck_autoencoder"] = {k: list(v.shape) for k, v in create_model_from_config(cfg).state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(inv, f, indent=0, sort_keys=True)
     print("done")
 
 
