@@ -25,6 +25,8 @@ extern "C" {
 /* library / device info: returns the ABI version; fills the gfx arch name the code objects target */
 int kalle_abi_version(void);
 const char* kalle_target_arch(void);
+/* name of the HIP error behind the calling thread's most recent KALLE_ERR_LAUNCH ("" if none) */
+const char* kalle_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM (bf16 MFMA, fp32 accumulate) with fused epilogue.

@@ -8,6 +8,11 @@ import ctypes
 import os
 import re
 
+# torch must be imported BEFORE libkalle_hip.so is dlopen'ed: the library's DT_NEEDED libamdhip64.so then resolves to
+# the HIP runtime torch already loaded, so both share one runtime (and one view of the device, streams and memory).
+# Loaded the other way round the process ends up with two HIP runtimes and ours reports hipErrorNoDevice.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "kalle_hip.h")
 LIB_PATH = os.path.join(HERE, "libkalle_hip.so")
@@ -91,4 +96,7 @@ def load():
 
 def check(code, what):
     if code != 0:
-        raise KalleError(f"{what} failed: {_ERR.get(code, code)}")
+        detail = ""
+        if code == -2 and _lib is not None:
+            detail = " [" + (_lib.kalle_last_error() or b"").decode() + "]"
+        raise KalleError(f"{what} failed: {_ERR.get(code, code)}{detail}")

@@ -503,7 +503,7 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
         attr = true;
     }
     dim3 grid((Nq + 127) / 128, H, B), block(256);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, lds, static_cast<hipStream_t>(stream), p);
+    KALLE_LAUNCH(attn_fwd_kernel, grid, block, lds, static_cast<hipStream_t>(stream), p);
     return kalle_check_launch();
 }
 
@@ -528,7 +528,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 
     const int64_t items = (int64_t)B * Nq * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st,
+    KALLE_LAUNCH(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st,
                        static_cast<const bf16_t*>(out), p.dout, ldo, delta, B, H, Nq);
     constexpr int lds = 2 * AT_TILE + 256 * 4;
     static bool attr = false;
@@ -539,7 +539,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<true>), dim3((Nk + 127) / 128, Hkv, B), dim3(256), lds, st, p);
-    hipLaunchKernelGGL((attn_bwd_kernel<false>), dim3((Nq + 127) / 128, H, B), dim3(256), lds, st, p);
+    KALLE_LAUNCH((attn_bwd_kernel<true>), dim3((Nk + 127) / 128, Hkv, B), dim3(256), lds, st, p);
+    KALLE_LAUNCH((attn_bwd_kernel<false>), dim3((Nq + 127) / 128, H, B), dim3(256), lds, st, p);
     return kalle_check_launch();
 }

@@ -70,7 +70,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
 
+// hipGetLastError() is sticky per thread: an earlier, unrelated HIP call of the host application (e.g. a
+// hipEventQuery that returned hipErrorNotReady) must not be reported as this launch's failure - clear it first.
+#define KALLE_LAUNCH(...)            \
+    do {                             \
+        (void)hipGetLastError();     \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
+extern "C" void kalle_set_last_error(const char* what);
 static inline int kalle_check_launch() {
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? KALLE_OK : KALLE_ERR_LAUNCH;
+    if (e == hipSuccess) return KALLE_OK;
+    kalle_set_last_error(hipGetErrorName(e));
+    return KALLE_ERR_LAUNCH;
 }

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void snake_kernel(const void* __restrict__ x, 
 extern "C" int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                                       int transposed, void* stream) {
     if (!v || !w_packed || d0 <= 0 || d1 <= 0 || ksize <= 0) return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(wn_fold_kernel, dim3(d0), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
+    KALLE_LAUNCH(wn_fold_kernel, dim3(d0), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
                        ksize, transposed);
     return kalle_check_launch();
 }
@@ -268,10 +268,10 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
-    if (xf && yf) hipLaunchKernelGGL((conv1d_kernel<true, true>), grid, block, 0, st, p);
-    else if (xf) hipLaunchKernelGGL((conv1d_kernel<true, false>), grid, block, 0, st, p);
-    else if (yf) hipLaunchKernelGGL((conv1d_kernel<false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv1d_kernel<false, false>), grid, block, 0, st, p);
+    if (xf && yf) KALLE_LAUNCH((conv1d_kernel<true, true>), grid, block, 0, st, p);
+    else if (xf) KALLE_LAUNCH((conv1d_kernel<true, false>), grid, block, 0, st, p);
+    else if (yf) KALLE_LAUNCH((conv1d_kernel<false, true>), grid, block, 0, st, p);
+    else KALLE_LAUNCH((conv1d_kernel<false, false>), grid, block, 0, st, p);
     return kalle_check_launch();
 }
 
@@ -290,10 +290,10 @@ extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const floa
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
-    if (xf && yf) hipLaunchKernelGGL((convT1d_kernel<true, true>), grid, block, 0, st, p);
-    else if (xf) hipLaunchKernelGGL((convT1d_kernel<true, false>), grid, block, 0, st, p);
-    else if (yf) hipLaunchKernelGGL((convT1d_kernel<false, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((convT1d_kernel<false, false>), grid, block, 0, st, p);
+    if (xf && yf) KALLE_LAUNCH((convT1d_kernel<true, true>), grid, block, 0, st, p);
+    else if (xf) KALLE_LAUNCH((convT1d_kernel<true, false>), grid, block, 0, st, p);
+    else if (yf) KALLE_LAUNCH((convT1d_kernel<false, true>), grid, block, 0, st, p);
+    else KALLE_LAUNCH((convT1d_kernel<false, false>), grid, block, 0, st, p);
     return kalle_check_launch();
 }
 
@@ -305,8 +305,8 @@ extern "C" int kalle_snake_beta_fwd(const void* x, void* y, int dtype, const flo
     if (g > 2048) g = 2048;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == KALLE_F32)
-        hipLaunchKernelGGL((snake_kernel<true>), dim3((unsigned)g), dim3(256), 0, st, x, y, alpha, beta, logscale, C, L, total);
+        KALLE_LAUNCH((snake_kernel<true>), dim3((unsigned)g), dim3(256), 0, st, x, y, alpha, beta, logscale, C, L, total);
     else
-        hipLaunchKernelGGL((snake_kernel<false>), dim3((unsigned)g), dim3(256), 0, st, x, y, alpha, beta, logscale, C, L, total);
+        KALLE_LAUNCH((snake_kernel<false>), dim3((unsigned)g), dim3(256), 0, st, x, y, alpha, beta, logscale, C, L, total);
     return kalle_check_launch();
 }

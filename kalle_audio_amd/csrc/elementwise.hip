@@ -1,6 +1,7 @@
 // HBM-bound elementwise / reduction kernels on the DiT train-step path (gfx950): vectorised 16-B
 // accesses, grid-stride loops capped at 2048 blocks, fp32 math on bf16 storage.
 // Reference call sites are cited per kernel.
+#include <stdio.h>
 #include "common.h"
 #include "../../include/kalle_hip.h"
 
@@ -342,14 +343,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int kalle_swiglu_fwd(const void* h, void* out, int64_t rows, int inner, void* stream) {
     if (!h || !out || rows <= 0 || inner <= 0 || (inner & 7)) return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
+    KALLE_LAUNCH(swiglu_fwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(h), static_cast<bf16_t*>(out), rows,
                        inner);
     return kalle_check_launch();
 }
 extern "C" int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64_t rows, int inner, void* stream) {
     if (!dout || !h || !dh || rows <= 0 || inner <= 0 || (inner & 7)) return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
+    KALLE_LAUNCH(swiglu_bwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(dout),
                        static_cast<const bf16_t*>(h), static_cast<bf16_t*>(dh), rows, inner);
     return kalle_check_launch();
@@ -357,22 +358,22 @@ extern "C" int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64
 extern "C" int kalle_silu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream) {
     if (!x || !y || n <= 0) return KALLE_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == KALLE_F32) hipLaunchKernelGGL((silu_fwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
-    else hipLaunchKernelGGL((silu_fwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
+    if (dtype == KALLE_F32) KALLE_LAUNCH((silu_fwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
+    else KALLE_LAUNCH((silu_fwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, n);
     return kalle_check_launch();
 }
 extern "C" int kalle_silu_bwd(const void* dy, const void* x, void* dx, int dtype, int64_t n, void* stream) {
     if (!dy || !x || !dx || n <= 0) return KALLE_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == KALLE_F32) hipLaunchKernelGGL((silu_bwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
-    else hipLaunchKernelGGL((silu_bwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
+    if (dtype == KALLE_F32) KALLE_LAUNCH((silu_bwd_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
+    else KALLE_LAUNCH((silu_bwd_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, dy, x, dx, n);
     return kalle_check_launch();
 }
 extern "C" int kalle_diffuse_fwd(const float* x, const float* noise, const float* t, float* x_t, float* target,
                                  int nbatch, int64_t per_sample, int objective, void* stream) {
     if (!x || !noise || !t || !x_t || !target || nbatch <= 0 || per_sample <= 0 || (objective != 0 && objective != 1))
         return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(diffuse_kernel, dim3(grid_for((int64_t)nbatch * per_sample, 256)), dim3(256), 0,
+    KALLE_LAUNCH(diffuse_kernel, dim3(grid_for((int64_t)nbatch * per_sample, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, noise, t, x_t, target, nbatch, per_sample, objective);
     return kalle_check_launch();
 }
@@ -381,13 +382,13 @@ extern "C" int kalle_mse_fwd(const float* out, const float* target, const uint8_
     if (!out || !target || !loss_acc || nbatch <= 0 || C <= 0 || T <= 0) return KALLE_ERR_ARG;
     int g = grid_for((int64_t)nbatch * C * T, 256);
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(mse_fwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), out, target, mask,
+    KALLE_LAUNCH(mse_fwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), out, target, mask,
                        loss_acc, diff, nbatch, C, T);
     return kalle_check_launch();
 }
 extern "C" int kalle_mse_finish(float* loss_acc, float* loss, float* diff, int64_t n, float weight, void* stream) {
     if (!loss_acc || n < 0) return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(mse_finish_kernel, dim3(diff ? grid_for(n, 256) : 1), dim3(256), 0,
+    KALLE_LAUNCH(mse_finish_kernel, dim3(diff ? grid_for(n, 256) : 1), dim3(256), 0,
                        static_cast<hipStream_t>(stream), loss_acc, loss, diff, n, weight);
     return kalle_check_launch();
 }
@@ -398,7 +399,7 @@ extern "C" int kalle_transpose_2d(const void* in, int in_dtype, int64_t in_batch
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((Cn + 31) / 32, (R + 31) / 32, nbatch), block(256);
     const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
-#define TL(I, O) hipLaunchKernelGGL((transpose_kernel<I, O>), grid, block, 0, st, in, out, R, Cn, in_batch_stride, \
+#define TL(I, O) KALLE_LAUNCH((transpose_kernel<I, O>), grid, block, 0, st, in, out, R, Cn, in_batch_stride, \
                                     out_batch_stride, in_ld, out_ld)
     if (i32 && o32) TL(true, true); else if (i32) TL(true, false); else if (o32) TL(false, true); else TL(false, false);
 #undef TL
@@ -414,7 +415,7 @@ extern "C" int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_st
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(grid_for((int64_t)nbatch * rows * (cols >> 2), 256)), block(256);
     const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
-#define CL(I, O) hipLaunchKernelGGL((copy_rows_kernel<I, O>), grid, block, 0, st, in, out, nbatch, rows, cols, \
+#define CL(I, O) KALLE_LAUNCH((copy_rows_kernel<I, O>), grid, block, 0, st, in, out, nbatch, rows, cols, \
                                     in_batch_stride, in_ld, out_batch_stride, out_ld, accumulate)
     if (i32 && o32) CL(true, true); else if (i32) CL(true, false); else if (o32) CL(false, true); else CL(false, false);
 #undef CL
@@ -425,7 +426,7 @@ extern "C" int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(grid_for(n, 256)), block(256);
     const bool i32 = in_dtype == KALLE_F32, o32 = out_dtype == KALLE_F32;
-#define CK(I, O) hipLaunchKernelGGL((cast_kernel<I, O>), grid, block, 0, st, in, out, n)
+#define CK(I, O) KALLE_LAUNCH((cast_kernel<I, O>), grid, block, 0, st, in, out, n)
     if (i32 && o32) CK(true, true); else if (i32) CK(true, false); else if (o32) CK(false, true); else CK(false, false);
 #undef CK
     return kalle_check_launch();
@@ -435,8 +436,8 @@ extern "C" int kalle_fourier_features(const float* t, const float* w, void* out,
     if (!t || !w || !out || nbatch <= 0 || half <= 0) return KALLE_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((nbatch * half + 255) / 256), block(256);
-    if (out_dtype == KALLE_F32) hipLaunchKernelGGL((fourier_kernel<true>), grid, block, 0, st, t, w, out, nbatch, half);
-    else hipLaunchKernelGGL((fourier_kernel<false>), grid, block, 0, st, t, w, out, nbatch, half);
+    if (out_dtype == KALLE_F32) KALLE_LAUNCH((fourier_kernel<true>), grid, block, 0, st, t, w, out, nbatch, half);
+    else KALLE_LAUNCH((fourier_kernel<false>), grid, block, 0, st, t, w, out, nbatch, half);
     return kalle_check_launch();
 }
 extern "C" int kalle_grad_cast(const float* g, const float* x_out, const float* x_in, const float* gate, int64_t ldg,
@@ -445,14 +446,14 @@ extern "C" int kalle_grad_cast(const float* g, const float* x_out, const float* 
     if (!g || !gb || nbatch <= 0 || rows_per_batch <= 0 || D <= 0 || (D & 1) || nbatch > 65535) return KALLE_ERR_ARG;
     if (gate && (!x_out || !x_in)) return KALLE_ERR_ARG;
     dim3 block(128), grid((D / 2 + 127) / 128, nbatch);
-    hipLaunchKernelGGL(grad_cast_kernel, grid, block, 0, static_cast<hipStream_t>(stream), g, x_out, x_in, gate, ldg,
+    KALLE_LAUNCH(grad_cast_kernel, grid, block, 0, static_cast<hipStream_t>(stream), g, x_out, x_in, gate, ldg,
                        row_mask, static_cast<bf16_t*>(gb), dgate, rows_per_batch, D);
     return kalle_check_launch();
 }
 extern "C" int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w, float* dw, int nbatch,
                                           int half, void* stream) {
     if (!dout || !t || !w || !dw || nbatch <= 0 || half <= 0) return KALLE_ERR_ARG;
-    hipLaunchKernelGGL(fourier_bwd_kernel, dim3((half + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
+    KALLE_LAUNCH(fourier_bwd_kernel, dim3((half + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream),
                        dout, t, w, dw, nbatch, half);
     return kalle_check_launch();
 }
@@ -462,11 +463,16 @@ extern "C" int kalle_adam_step(float* param, const float* grad, float* exp_avg, 
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return KALLE_ERR_ARG;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+    KALLE_LAUNCH(adam_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
                        grad, exp_avg, exp_avg_sq, static_cast<bf16_t*>(param_bf16), n, lr, beta1, beta2, eps,
                        weight_decay, decoupled, bc1, bc2, grad_scale);
     return kalle_check_launch();
 }
 
+static thread_local char g_last_error[128] = "";
+extern "C" void kalle_set_last_error(const char* what) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s", what ? what : "");
+}
+extern "C" const char* kalle_last_error(void) { return g_last_error; }
 extern "C" int kalle_abi_version(void) { return 1; }
 extern "C" const char* kalle_target_arch(void) { return "gfx950"; }

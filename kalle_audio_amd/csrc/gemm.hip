@@ -277,7 +277,7 @@ int launch(const GemmParams& p, hipStream_t st) {
     }
     const int tiles_m = (p.M + BM - 1) / BM;
     dim3 grid(tiles_m * p.tiles_n), block(256);
-    hipLaunchKernelGGL((gemm_bf16_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
+    KALLE_LAUNCH((gemm_bf16_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
 

@@ -377,10 +377,10 @@ extern "C" int kalle_layernorm_fwd(const void* x, int x_dtype, const float* gamm
     dim3 grid((rows + 3) / 4), block(256);
 #define CALL(N)                                                                                                    \
     if (x_dtype == KALLE_F32)                                                                                      \
-        hipLaunchKernelGGL((ln_fwd_kernel<N, true>), grid, block, 0, st, x, gamma, beta, scale, shift, ld_mod, rpb, \
+        KALLE_LAUNCH((ln_fwd_kernel<N, true>), grid, block, 0, st, x, gamma, beta, scale, shift, ld_mod, rpb, \
                            static_cast<bf16_t*>(y), mean, rstd, rows, D, eps);                                     \
     else                                                                                                           \
-        hipLaunchKernelGGL((ln_fwd_kernel<N, false>), grid, block, 0, st, x, gamma, beta, scale, shift, ld_mod,    \
+        KALLE_LAUNCH((ln_fwd_kernel<N, false>), grid, block, 0, st, x, gamma, beta, scale, shift, ld_mod,    \
                            rpb, static_cast<bf16_t*>(y), mean, rstd, rows, D, eps);
     DISPATCH_NCH(D, CALL);
 #undef CALL
@@ -403,10 +403,10 @@ extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, c
     dim3 grid(kalle_layernorm_bwd_parts(rows)), block(256);
 #define CALL(N)                                                                                                   \
     if (x_dtype == KALLE_F32)                                                                                     \
-        hipLaunchKernelGGL((ln_bwd_kernel<N, true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma, \
+        KALLE_LAUNCH((ln_bwd_kernel<N, true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma, \
                            scale, ld_mod, rpb, mean, rstd, dres, dx_out, dgamma_part, dbeta_part, rows, D);       \
     else                                                                                                          \
-        hipLaunchKernelGGL((ln_bwd_kernel<N, false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,      \
+        KALLE_LAUNCH((ln_bwd_kernel<N, false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,      \
                            gamma, scale, ld_mod, rpb, mean, rstd, dres, dx_out, dgamma_part, dbeta_part, rows, D);
     DISPATCH_NCH(D, CALL);
 #undef CALL
@@ -421,10 +421,10 @@ extern "C" int kalle_adaln_mod_bwd(const void* dy, const void* x, int x_dtype, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 block(128), grid((D / 2 + 127) / 128, nbatch);
     if (x_dtype == KALLE_F32)
-        hipLaunchKernelGGL((adaln_mod_bwd_kernel<true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma,
+        KALLE_LAUNCH((adaln_mod_bwd_kernel<true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma,
                            beta, mean, rstd, dscale, dshift, ld_mod, rows_per_batch, D);
     else
-        hipLaunchKernelGGL((adaln_mod_bwd_kernel<false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,
+        KALLE_LAUNCH((adaln_mod_bwd_kernel<false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,
                            gamma, beta, mean, rstd, dscale, dshift, ld_mod, rows_per_batch, D);
     return kalle_check_launch();
 }
@@ -437,16 +437,16 @@ extern "C" int kalle_rmsnorm_fwd(const void* x, int x_dtype, const float* scale,
     dim3 grid((rows + 3) / 4), block(256);
 #define CALL(N)                                                                                                    \
     if (x_dtype == KALLE_F32 && y_dtype == KALLE_F32)                                                              \
-        hipLaunchKernelGGL((rms_fwd_kernel<N, true, true>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms,  \
+        KALLE_LAUNCH((rms_fwd_kernel<N, true, true>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms,  \
                            rows, D, eps);                                                                          \
     else if (x_dtype == KALLE_F32)                                                                                 \
-        hipLaunchKernelGGL((rms_fwd_kernel<N, true, false>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms, \
+        KALLE_LAUNCH((rms_fwd_kernel<N, true, false>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms, \
                            rows, D, eps);                                                                          \
     else if (y_dtype == KALLE_F32)                                                                                 \
-        hipLaunchKernelGGL((rms_fwd_kernel<N, false, true>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms, \
+        KALLE_LAUNCH((rms_fwd_kernel<N, false, true>), grid, block, 0, st, x, scale, ld_scale, rpb, y, rrms, \
                            rows, D, eps);                                                                          \
     else                                                                                                           \
-        hipLaunchKernelGGL((rms_fwd_kernel<N, false, false>), grid, block, 0, st, x, scale, ld_scale, rpb, y,      \
+        KALLE_LAUNCH((rms_fwd_kernel<N, false, false>), grid, block, 0, st, x, scale, ld_scale, rpb, y,      \
                            rrms, rows, D, eps);
     DISPATCH_NCH(D, CALL);
 #undef CALL
@@ -462,16 +462,16 @@ extern "C" int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, in
     dim3 grid(kalle_layernorm_bwd_parts(rows)), block(256);
 #define CALL(N)                                                                                                     \
     if (x_dtype == KALLE_F32 && dy_dtype == KALLE_F32)                                                              \
-        hipLaunchKernelGGL((rms_bwd_kernel<N, true, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms,  \
+        KALLE_LAUNCH((rms_bwd_kernel<N, true, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms,  \
                            dx, dscale_part, rows, D);                                                               \
     else if (x_dtype == KALLE_F32)                                                                                  \
-        hipLaunchKernelGGL((rms_bwd_kernel<N, true, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
+        KALLE_LAUNCH((rms_bwd_kernel<N, true, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
                            dx, dscale_part, rows, D);                                                               \
     else if (dy_dtype == KALLE_F32)                                                                                 \
-        hipLaunchKernelGGL((rms_bwd_kernel<N, false, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
+        KALLE_LAUNCH((rms_bwd_kernel<N, false, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
                            dx, dscale_part, rows, D);                                                               \
     else                                                                                                            \
-        hipLaunchKernelGGL((rms_bwd_kernel<N, false, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb,      \
+        KALLE_LAUNCH((rms_bwd_kernel<N, false, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb,      \
                            rrms, dx, dscale_part, rows, D);
     DISPATCH_NCH(D, CALL);
 #undef CALL
@@ -493,8 +493,8 @@ extern "C" int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out
     slabs = (rows + rps - 1) / rps;
     dim3 grid(gx, slabs), block(256);
     if (in_dtype == KALLE_F32)
-        hipLaunchKernelGGL((colsum_kernel<true>), grid, block, 0, st, in, ld, out, rows, cols, rps);
+        KALLE_LAUNCH((colsum_kernel<true>), grid, block, 0, st, in, ld, out, rows, cols, rps);
     else
-        hipLaunchKernelGGL((colsum_kernel<false>), grid, block, 0, st, in, ld, out, rows, cols, rps);
+        KALLE_LAUNCH((colsum_kernel<false>), grid, block, 0, st, in, ld, out, rows, cols, rps);
     return kalle_check_launch();
 }

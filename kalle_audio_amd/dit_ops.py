@@ -1,9 +1,9 @@
 """Forward / backward of the DiT building blocks expressed as sequences of C-ABI kernel launches.
 
 Everything here is "manual autograd": each *_fwd returns the tensors its *_bwd needs, each *_bwd returns input
-and parameter gradients.  The torch.autograd.Function shims in functional.py and the data-parallel trainer in
-engine.py are both thin layers over these functions, so the drop-in modules and the benchmarked train step run
-exactly the same kernels.
+gradients and hands parameter gradients to a GradOut.  The torch.autograd.Function shims in functional.py and the
+data-parallel trainer in engine.py are both thin layers over these functions, so the drop-in modules and the
+benchmarked train step run exactly the same kernels.
 
 Dtype policy: residual stream fp32, GEMM operands bf16, GEMM accumulation fp32, parameter gradients
 fp32.  Reference: stable_audio_tools/models/transformer.py (line numbers per function).
@@ -42,9 +42,44 @@ def rope_tables(freqs):
     return f.cos().contiguous(), f.sin().contiguous()
 
 
-def wgrad(dy, x):
-    """dW[N,K] = dy[M,N]^T @ x[M,K] (fp32 out)"""
-    return ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+class GradOut:
+    """Destination of parameter gradients.  Without sinks every gradient is a fresh fp32 tensor in `.grads`
+    (autograd mode).  With `sinks` (name -> fp32 view into the trainer's flat gradient bucket) the wgrad GEMMs and
+    column sums write straight into the bucket (accumulating on later micro-batches) and `.grads[name]` is None."""
+
+    def __init__(self, sinks=None, accumulate=False, prefix=""):
+        self.sinks = sinks or {}
+        self.accumulate = accumulate
+        self.prefix = prefix
+        self.grads = {}
+
+    def _sink(self, name):
+        return self.sinks.get(self.prefix + name)
+
+    def wgrad(self, name, dy, x):
+        """dW[N,K] = dy[M,N]^T @ x[M,K]"""
+        s = self._sink(name)
+        if s is not None:
+            ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=self.accumulate)
+            self.grads[name] = None
+        else:
+            self.grads[name] = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+
+    def colsum(self, name, src):
+        s = self._sink(name)
+        if s is not None:
+            ops.colsum(src, out=s.view(-1), accumulate=self.accumulate)
+            self.grads[name] = None
+        else:
+            self.grads[name] = ops.colsum(src)
+
+    def ln(self, name, dy, x, gamma, mean, rstd, **kw):
+        """LayerNorm backward: returns dx; dgamma goes to the sink / grads."""
+        s = self._sink(name)
+        dx, dgamma, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma_out=s.view(-1) if s is not None else None,
+                                          accumulate=self.accumulate if s is not None else False, **kw)
+        self.grads[name] = None if s is not None else dgamma
+        return dx
 
 
 def dgrad(dy, w, **kw):
@@ -64,19 +99,17 @@ def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, o
     return out, (qkv, ao, lse)
 
 
-def self_attn_bwd(gb, h, saved, wqkv, wo, B, N, H, rope, mask8):
-    """gb: bf16 [B*N, D] gradient w.r.t. the to_out GEMM result. Returns dh (bf16), dWqkv, dWo (fp32)."""
+def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_attn."):
+    """gb: bf16 [B*N, D] gradient w.r.t. the to_out GEMM result. Returns dh (bf16)."""
     qkv, ao, lse = saved
     D = H * 64
-    ao2 = ao.view(B * N, D)
-    dwo = wgrad(gb, ao2)
+    go.wgrad(pre + "to_out.weight", gb, ao.view(B * N, D))
     dao = dgrad(gb, wo)
     dqkv = torch.empty_like(qkv)
     ops.attention_bwd(qkv, qkv, qkv, ao, dao, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
                       ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
-    dwqkv = wgrad(dqkv, h)
-    dh = dgrad(dqkv, wqkv)
-    return dh, dwqkv, dwo
+    go.wgrad(pre + "to_qkv.weight", dqkv, h)
+    return dgrad(dqkv, wqkv)
 
 
 def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None):
@@ -92,27 +125,29 @@ def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_d
     return out, (q, kv, co, lse)
 
 
-def cross_attn_bwd(gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_acc=None):
-    """Returns dh (bf16), dctx (fp32 [B*S, Dc], accumulated into dctx_acc when given), dWq, dWkv, dWo."""
+def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_acc=None, want_dctx=True,
+                   pre="cross_attn."):
+    """Returns dh (bf16), dctx (fp32 [B*S, Dc]; accumulated into dctx_acc when given; None if not wanted)."""
     q, kv, co, lse = saved
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
-    co2 = co.view(B * N, D)
-    dwo = wgrad(gb, co2)
+    go.wgrad(pre + "to_out.weight", gb, co.view(B * N, D))
     dco = dgrad(gb, wo)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     ops.attention_bwd(q, kv, kv, co, dco, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
                       v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
-    dwq = wgrad(dq, h)
+    go.wgrad(pre + "to_q.weight", dq, h)
     dh = dgrad(dq, wq)
-    dwkv = wgrad(dkv, ctx)
-    if dctx_acc is not None:
-        dctx = dgrad(dkv, wkv, out=dctx_acc, accumulate=True)
-    else:
-        dctx = dgrad(dkv, wkv, out_dtype=F32)
-    return dh, dctx, dwq, dwkv, dwo
+    go.wgrad(pre + "to_kv.weight", dkv, ctx)
+    dctx = None
+    if want_dctx:
+        if dctx_acc is not None:
+            dctx = dgrad(dkv, wkv, out=dctx_acc, accumulate=True)
+        else:
+            dctx = dgrad(dkv, wkv, out_dtype=F32)
+    return dh, dctx
 
 
 # ------------------------------------------------------------------------------------------------ feed-forward
@@ -124,19 +159,27 @@ def ff_fwd(h, w1, b1, w2, b2, N, residual=None, gate=None, out_dtype=F32):
     return out, (hf, act)
 
 
-def ff_bwd(gb, h, saved, w1, w2, want_bias=True):
+def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff."):
     hf, act = saved
-    dw2 = wgrad(gb, act)
-    db2 = ops.colsum(gb) if want_bias else None
+    go.wgrad(pre + "2.weight", gb, act)
+    if want_bias:
+        go.colsum(pre + "2.bias", gb)
     dact = dgrad(gb, w2)
     dhf = ops.swiglu_bwd(dact, hf)
-    dw1 = wgrad(dhf, h)
-    db1 = ops.colsum(dhf) if want_bias else None
-    dh = dgrad(dhf, w1)
-    return dh, dw1, db1, dw2, db2
+    go.wgrad(pre + "0.proj.weight", dhf, h)
+    if want_bias:
+        go.colsum(pre + "0.proj.bias", dhf)
+    return dgrad(dhf, w1)
 
 
 # ------------------------------------------------------------------------------------------------ transformer block
+def _beta(norm):
+    b = getattr(norm, "beta", None)
+    if isinstance(b, torch.nn.Parameter):
+        return f32_of(b)
+    return None  # zero buffer (transformer.py:188): adding it is a no-op
+
+
 def block_params(blk):
     """Gather the kernel-ready views of one TransformerBlock's parameters (bf16 weights, fp32 vectors)."""
     p = SimpleNamespace()
@@ -165,15 +208,6 @@ def block_params(blk):
     return p
 
 
-def _beta(norm):
-    b = getattr(norm, "beta", None)
-    if b is None:
-        return None
-    if isinstance(b, torch.nn.Parameter):
-        return f32_of(b)
-    return None  # zero buffer (transformer.py:188): adding it is a no-op
-
-
 BLOCK_PARAM_ORDER = ("pre_norm.gamma", "self_attn.to_qkv.weight", "self_attn.to_out.weight",
                      "cross_attend_norm.gamma", "cross_attn.to_q.weight", "cross_attn.to_kv.weight",
                      "cross_attn.to_out.weight", "ff_norm.gamma", "ff.ff.0.proj.weight", "ff.ff.0.proj.bias",
@@ -198,7 +232,8 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
     sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s)
     xcur = sv.x1
     # cross-attention (never modulated, 670-671)
-    if p.cross and ctx is not None:
+    sv.has_cross = p.cross and ctx is not None
+    if sv.has_cross:
         sv.h2, sv.mean2, sv.rstd2 = ops.layernorm_fwd(xcur, p.g2, p.beta2)
         sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur)
         xcur = sv.x2
@@ -207,15 +242,13 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
     y, sv.ff = ff_fwd(sv.h3, p.w1, p.b1, p.w2, p.b2, N, residual=xcur, gate=g_f)
     sv.y = y if ada else None
     sv.ada = ada
-    sv.has_cross = p.cross and ctx is not None
     return y, sv
 
 
-def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, dctx_acc=None):
-    """g: fp32 [B*N, D] gradient of the block output.  Returns (dx fp32, dctx fp32|None, dglobal fp32|None,
-    grads dict keyed like BLOCK_PARAM_ORDER)."""
+def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=None, want_dctx=True):
+    """g: fp32 [B*N, D] gradient of the block output.  Returns (dx fp32, dctx fp32|None, dglobal fp32|None, go)."""
     D = g.shape[-1]
-    gr = {}
+    go = go or GradOut()
     ada = sv.ada
     mod = sv.mod if ada else None
     sl = (lambda i: mod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
@@ -229,21 +262,19 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, dctx_acc=None):
         dsl(5).copy_(dg)
     else:
         gb = ops.cast(g, BF16)
-    dh3, gr["ff.ff.0.proj.weight"], gr["ff.ff.0.proj.bias"], gr["ff.ff.2.weight"], gr["ff.ff.2.bias"] = \
-        ff_bwd(gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None)
+    dh3 = ff_bwd(go, gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh3, xin_ff, p.g3, p.beta3, sv.mean3, sv.rstd3, B, N)
         dsl(3).copy_(dsc)
         dsl(4).copy_(dsh)
-    g2, gr["ff_norm.gamma"], _ = ops.layernorm_bwd(dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3),
-                                                    rows_per_batch=N, dres=g)
+    g2 = go.ln("ff_norm.gamma", dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3), rows_per_batch=N, dres=g)
     # ---- cross-attention branch
     dctx = None
     if sv.has_cross:
         g2b = ops.cast(g2, BF16)
-        dh2, dctx, gr["cross_attn.to_q.weight"], gr["cross_attn.to_kv.weight"], gr["cross_attn.to_out.weight"] = \
-            cross_attn_bwd(g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc)
-        g1, gr["cross_attend_norm.gamma"], _ = ops.layernorm_bwd(dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2)
+        dh2, dctx = cross_attn_bwd(go, g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc,
+                                   want_dctx)
+        g1 = go.ln("cross_attend_norm.gamma", dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2)
     else:
         g1 = g2
     # ---- self-attention branch:  x1 = x + SA(LN(x)*(1+sc)+sh) * sigmoid(1-gate)   (masked rows contribute 0)
@@ -254,18 +285,16 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, dctx_acc=None):
         g1b, _ = ops.grad_cast(g1, B, N, row_mask=mask8)
     else:
         g1b = ops.cast(g1, BF16)
-    dh1, gr["self_attn.to_qkv.weight"], gr["self_attn.to_out.weight"] = \
-        self_attn_bwd(g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8)
+    dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
         dsl(0).copy_(dsc)
         dsl(1).copy_(dsh)
-    dx, gr["pre_norm.gamma"], _ = ops.layernorm_bwd(dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0),
-                                                     rows_per_batch=N, dres=g1)
+    dx = go.ln("pre_norm.gamma", dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0), rows_per_batch=N, dres=g1)
     dglobal = None
     if ada:
         dmb = ops.cast(dmod, BF16)
-        gr["to_scale_shift_gate.1.weight"] = wgrad(dmb, sv.sgb)
+        go.wgrad("to_scale_shift_gate.1.weight", dmb, sv.sgb)
         dsg = dgrad(dmb, p.wmod, out_dtype=F32)
         dglobal = ops.silu_bwd(dsg, sv.x_global)
-    return dx, dctx, dglobal, gr
+    return dx, dctx, dglobal, go

@@ -1,0 +1,241 @@
+"""Data-parallel DiT trainer: the MI355X re-expression of the reference's DDP step.
+
+Reference shape of the step: train_offline.py:203-259 (zero_grad -> forward -> loss -> accelerator.backward [DDP
+bucketed NCCL all-reduce] -> optimizer.step -> scheduler.step -> barrier) around the stable_audio_tools objective
+(training/diffusion.py:365-399).  Here:
+
+  * one process per GPU (torchrun / env RANK, LOCAL_RANK, WORLD_SIZE), torch.distributed backend "nccl" == RCCL
+    over xGMI; per-GPU data shards, no data-path collective other than the gradient all-reduce;
+  * all trainable parameters live in ONE flat fp32 master buffer (+ a flat bf16 compute mirror the GEMMs read and a
+    flat fp32 gradient buffer); module parameters are views, so state_dict()/load_state_dict() keep working;
+  * buckets = one per TransformerBlock (reverse layer order) + one for everything else; the wgrad GEMMs write
+    straight into the bucket, and the bucket's all-reduce is issued the moment the block's backward has been queued -
+    RCCL runs it on its own stream behind an event, overlapping the remaining backward;
+  * one fused Adam/AdamW launch over the flat buffers updates master weights, moments and the bf16 mirror and folds
+    the 1/world_size gradient averaging in (no separate scale pass, no per-step host sync, no barrier).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim-style front end of kalle_adam_step (maps the reference's optional deepspeed FusedAdam,
+    training/utils.py:88-90).  adam_w_mode=False gives torch.optim.Adam's L2 weight decay."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adam_w_mode=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adam_w_mode=adam_w_mode))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+                st["step"] += 1
+                grad = p.grad if p.grad.dtype == torch.float32 else p.grad.float()
+                ops.adam_step(p.data, grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], None, lr=g["lr"],
+                              beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                              decoupled=g["adam_w_mode"], step=st["step"])
+        return loss
+
+
+def cosine_with_warmup(step, warmup_steps, total_steps):
+    """transformers.get_cosine_schedule_with_warmup (train_offline.py:99-104) as a pure function of the step."""
+    if step < warmup_steps:
+        return step / max(1, warmup_steps)
+    prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun). Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatBuckets:
+    """Flat fp32 parameter / gradient storage partitioned into all-reduce buckets.  Device-agnostic (the gloo CPU
+    tests exercise exactly this class); only the optimizer launch needs the GPU."""
+
+    def __init__(self, named_params, bucket_of, device, with_bf16=True, align=64):
+        """named_params: list[(name, Parameter)] (trainable only); bucket_of: name -> bucket key (ordered by first
+        appearance)."""
+        self.names = [n for n, _ in named_params]
+        order = []
+        for n, _ in named_params:
+            k = bucket_of(n)
+            if k not in order:
+                order.append(k)
+        self.bucket_keys = order
+        self.slices = {}          # name -> (start, numel)
+        self.bucket_range = {}    # key -> (start, end)
+        off = 0
+        for k in order:
+            start = off
+            for n, p in named_params:
+                if bucket_of(n) != k:
+                    continue
+                self.slices[n] = (off, p.numel())
+                off += (p.numel() + align - 1) // align * align
+            self.bucket_range[k] = (start, off)
+        self.total = off
+        self.param = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.param_bf16 = torch.zeros(off, device=device, dtype=torch.bfloat16) if with_bf16 else None
+        with torch.no_grad():
+            for n, p in named_params:
+                s, ne = self.slices[n]
+                self.param[s:s + ne].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                p.data = self.param[s:s + ne].view(p.shape)
+                p.grad = self.grad[s:s + ne].view(p.shape)
+                if with_bf16:
+                    self.param_bf16[s:s + ne].copy_(self.param[s:s + ne])
+                    p._kalle_bf16_pinned = self.param_bf16[s:s + ne].view(p.shape)
+        self.params = dict(named_params)
+
+    def grad_view(self, name):
+        s, ne = self.slices[name]
+        return self.grad[s:s + ne].view(self.params[name].shape)
+
+    def bucket_grad(self, key):
+        a, b = self.bucket_range[key]
+        return self.grad[a:b]
+
+
+class DataParallelTrainer:
+    """Owns flat buffers, bucketed gradient all-reduce and the fused optimizer for a DiT (any module tree whose
+    TransformerBlocks come from kalle_audio_amd.stable_audio_tools.models.transformer)."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="Adam",
+                 grad_accum_steps=1, lr_schedule=None, process_group=None, comm_dtype=torch.float32):
+        from .stable_audio_tools.models.transformer import TransformerBlock
+        self.model = model
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.pg = process_group
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.decoupled = optimizer.lower() in ("adamw", "fusedadam")
+        self.grad_accum_steps = max(1, grad_accum_steps)
+        self.lr_schedule = lr_schedule
+        self.comm_dtype = comm_dtype
+        self.step_count = 0
+        self.micro = 0
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        device = named[0][1].device
+        # bucket key: the owning TransformerBlock's module path, or "_rest"
+        self.blocks = [(n, m) for n, m in model.named_modules() if isinstance(m, TransformerBlock)]
+        prefixes = [n + "." for n, _ in self.blocks]
+
+        def bucket_of(name):
+            for pre in prefixes:
+                if name.startswith(pre):
+                    return pre
+            return "_rest"
+
+        # identical initial weights on every rank (rank 0 broadcasts), as DDP does at wrap time
+        if self.world > 1:
+            for _, p in named:
+                dist.broadcast(p.data, src=0, group=self.pg)
+        self.flat = FlatBuckets(named, bucket_of, device)
+        self.exp_avg = torch.zeros_like(self.flat.param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.param)
+        self._pending = []
+        for n, blk in self.blocks:
+            pre = n + "."
+            blk._kalle_grad_sinks = {k[len(pre):]: self.flat.grad_view(k) for k in self.flat.names if k.startswith(pre)}
+            blk._kalle_grad_accumulate = False
+            blk._kalle_bucket_key = pre
+            blk._kalle_on_backward_done = self._on_block_done
+
+    # -- gradient communication ---------------------------------------------------------------------------
+    def _allreduce(self, buf):
+        if self.world == 1:
+            return
+        if self.comm_dtype == torch.float32 or not buf.is_cuda:
+            self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None))
+        else:
+            low = ops.cast(buf, self.comm_dtype)
+            self._pending.append((dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), low, buf))
+
+    def _on_block_done(self, blk):
+        """called (from autograd's backward) right after a block's backward kernels were queued"""
+        if self._boundary():
+            self._allreduce(self.flat.bucket_grad(blk._kalle_bucket_key))
+
+    def _boundary(self):
+        return (self.micro + 1) % self.grad_accum_steps == 0
+
+    def _finish_comm(self):
+        if self._boundary():
+            self._allreduce(self.flat.bucket_grad("_rest")) if "_rest" in self.flat.bucket_range else None
+        for work, low, dst in self._pending:
+            work.wait()
+            if low is not None:
+                ops.copy_rows(low, dst, 1, 1, dst.numel(), 0, dst.numel(), 0, dst.numel())
+        self._pending = []
+
+    # -- one micro-batch ------------------------------------------------------------------------------------
+    def backward(self, loss):
+        first = self.micro % self.grad_accum_steps == 0
+        for _, blk in self.blocks:
+            blk._kalle_grad_accumulate = not first
+        if first and "_rest" in self.flat.bucket_range:
+            self.flat.bucket_grad("_rest").zero_()     # autograd accumulates (+=) into these views
+        loss.backward()
+        self._finish_comm()
+        if self._boundary():
+            self.optimizer_step()
+        self.micro += 1
+
+    def optimizer_step(self):
+        self.step_count += 1
+        lr = self.lr * (self.lr_schedule(self.step_count) if self.lr_schedule else 1.0)
+        f = self.flat
+        ops.adam_step(f.param, f.grad, self.exp_avg, self.exp_avg_sq, f.param_bf16, lr=lr, beta1=self.betas[0],
+                      beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, decoupled=self.decoupled,
+                      step=self.step_count, grad_scale=1.0 / (self.world * self.grad_accum_steps))
+
+    def train_step(self, diffusion, latents, t, noise, cond, objective="v", padding_mask=None):
+        """fwd + bwd + all-reduce + optimizer for one micro-batch. Returns the (device) loss tensor, no host sync."""
+        from .stable_audio_tools.training.diffusion import diffusion_train_step
+        loss, _ = diffusion_train_step(diffusion, latents, t, noise, cond, objective=objective,
+                                       padding_mask=padding_mask)
+        self.backward(loss)
+        return loss.detach()
+
+    # -- checkpointing (reference: weights only, train_offline.py:261-263; here optimizer state too) -----------
+    def state_dict(self):
+        return {"model": self.model.state_dict(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd["model"], strict=False)
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = sd["step"]
+        self.resync_bf16()
+
+    def resync_bf16(self):
+        """after loading weights into the fp32 views: refresh the bf16 compute mirror"""
+        self.flat.param_bf16.copy_(self.flat.param)

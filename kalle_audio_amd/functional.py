@@ -62,7 +62,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _like(D.dgrad(gb, wb), ctx.x_dtype).view(ctx.shp)
         if ctx.needs_input_grad[1]:
-            dw = D.wgrad(gb, xb)
+            dw = ops.gemm(gb, xb, a_kmajor=True, b_kmajor=True, out_dtype=F32)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(gb)
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -256,8 +256,15 @@ class TransformerBlockFn(torch.autograd.Function):
         B, N, S, Dm = ctx.dims
         p = D.block_params(blk)
         gf = _to_f32(g.contiguous()).view(B * N, Dm)
-        dx, dctx, dglobal, gr = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S)
+        sinks = getattr(blk, "_kalle_grad_sinks", None)
+        go = D.GradOut(sinks, getattr(blk, "_kalle_grad_accumulate", False)) if sinks else D.GradOut()
+        dx, dctx, dglobal, go = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
+                                            want_dctx=ctx.needs_input_grad[2])
+        gr = go.grads
         ctx.sv = None
+        hook = getattr(blk, "_kalle_on_backward_done", None)
+        if hook is not None:
+            hook(blk)
         xdt, cdt, gdt = ctx.dtypes
         dx = _like(dx, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
         if dctx is not None and ctx.needs_input_grad[2]:
@@ -329,9 +336,11 @@ class AttentionFn(torch.autograd.Function):
             gb = _to_bf16(gf)
         if ctx.cross:
             cb, S, km, has_ctx = ctx.extra
-            dh, dctx, dwq, dwkv, dwo = D.cross_attn_bwd(gb, ctx.h, cb, ctx.sv, D.bf16_of(mod.to_q.weight),
-                                                        D.bf16_of(mod.to_kv.weight), D.bf16_of(mod.to_out.weight),
-                                                        B, N, S, H, km)
+            go = D.GradOut()
+            dh, dctx = D.cross_attn_bwd(go, gb, ctx.h, cb, ctx.sv, D.bf16_of(mod.to_q.weight),
+                                        D.bf16_of(mod.to_kv.weight), D.bf16_of(mod.to_out.weight), B, N, S, H, km,
+                                        pre="")
+            dwq, dwkv, dwo = go.grads["to_q.weight"], go.grads["to_kv.weight"], go.grads["to_out.weight"]
             dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
             dc = None
             if has_ctx:
@@ -339,8 +348,10 @@ class AttentionFn(torch.autograd.Function):
             else:
                 dx = dx + dctx.view(B, N, Dm).to(dx.dtype)  # kv_input == x: tape-level add of two input gradients
             return (None, dx, dc, None, None, None, dwq, dwkv, dwo)
-        dh, dwqkv, dwo = D.self_attn_bwd(gb, ctx.h, ctx.sv, D.bf16_of(mod.to_qkv.weight),
-                                         D.bf16_of(mod.to_out.weight), B, N, H, rope, mask8)
+        go = D.GradOut()
+        dh = D.self_attn_bwd(go, gb, ctx.h, ctx.sv, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight),
+                             B, N, H, rope, mask8, pre="")
+        dwqkv, dwo = go.grads["to_qkv.weight"], go.grads["to_out.weight"]
         dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
         return (None, dx, None, None, None, None, dwqkv, dwo)
 
@@ -363,7 +374,10 @@ class FeedForwardFn(torch.autograd.Function):
         shp, xdt, has_bias = ctx.meta
         w1, w2 = ctx.ws
         gb = _to_bf16(g.contiguous().view(-1, w2.shape[0]))
-        dh, dw1, db1, dw2, db2 = D.ff_bwd(gb, ctx.h, ctx.sv, D.bf16_of(w1), D.bf16_of(w2), want_bias=has_bias)
+        go = D.GradOut()
+        dh = D.ff_bwd(go, gb, ctx.h, ctx.sv, D.bf16_of(w1), D.bf16_of(w2), want_bias=has_bias, pre="")
+        dw1, db1 = go.grads["0.proj.weight"], go.grads.get("0.proj.bias")
+        dw2, db2 = go.grads["2.weight"], go.grads.get("2.bias")
         return None, _like(dh, xdt if xdt in (F32, BF16) else F32).view(shp), dw1, db1, dw2, db2
 
 

@@ -79,9 +79,23 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
         assert gate.dtype == torch.float32
     if residual is not None:
         assert residual.dtype == torch.float32
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.kalle_gemm_bf16(_p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc, _dt(out),
                               M, N, K, ctypes.byref(ep), _stream()), "kalle_gemm_bf16")
+    if prof is not None:
+        e1.record()
+        variant = "gemm_bf16_kernel<%d,%d,%d>" % (int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32))
+        prof.append((variant, 2.0 * M * N * K, e0, e1))
     return out
+
+
+# bench.py sets this to a list to collect (kernel variant, algorithmic flops, start event, end event) per GEMM launch:
+# HIP events recorded on the launch stream, read back after the timed region (no host sync while timing).
+KERNEL_TIMER = None
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -98,8 +112,9 @@ def layernorm_fwd(x, gamma, beta=None, scale=None, shift=None, rows_per_batch=0,
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=None, dx_out=None, want_dbeta=False):
-    """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None)"""
+def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=None, dx_out=None, want_dbeta=False,
+                  dgamma_out=None, accumulate=False):
+    """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None); dgamma_out (+accumulate) writes dgamma in place"""
     lib = _lib.load()
     rows, D = _rows2d(x)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
@@ -112,7 +127,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=N
     check(lib.kalle_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
                                   _p(rstd), _p(dres), _p(dx_out), _p(dgp), _p(dbp), rows, D, _stream()),
           "kalle_layernorm_bwd")
-    dgamma = colsum(dgp)
+    dgamma = colsum(dgp, out=dgamma_out, accumulate=accumulate)
     dbeta = colsum(dbp) if want_dbeta else None
     return dx_out, dgamma, dbeta
 
