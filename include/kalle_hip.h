@@ -61,6 +61,10 @@ int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int
                     void* C, int64_t ldc, int c_dtype, int M, int N, int K,
                     const kalle_gemm_epilogue* ep, void* stream);
 
+/* which kernel the calling thread's most recent kalle_gemm_bf16 used: low byte 1 = gemm_bf16_kernel (128x128,
+ * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 64 == 0); bits 8.. = split-K factor */
+int kalle_gemm_last_plan(void);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (bias-less gamma, eps 1e-5) with optional adaLN modulation - one wavefront per row.
  *   y = ((x-mean)*rstd*gamma + beta) * (1 + scale[b]) + shift[b]        (transformer.py:173-192, 660-665, 677-679)

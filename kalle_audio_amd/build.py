@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkalle_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "attention.hip", "conv1d.hip"]
+SOURCES = ["gemm.hip", "gemm2.hip", "norm.hip", "elementwise.hip", "attention.hip", "conv1d.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-value"]
 
@@ -26,7 +26,7 @@ def build(verbose=True, force=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "kalle_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "kalle_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     for s in srcs:

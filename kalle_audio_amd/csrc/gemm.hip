@@ -14,7 +14,7 @@
 //   k-major image:      [64][128] bf16, 288-B row stride, odd 8-row k-blocks stored with rows 0-3 <-> 4-7 swapped
 //                       -> ds_read_b64_tr_b16 (hardware transpose read) conflict-free
 // Epilogue: accumulators -> LDS fp32 tile -> coalesced 16-B row stores with bias / adaLN gate / residual / accumulate.
-#include "common.h"
+#include "gemm_common.h"
 #include "../../include/kalle_hip.h"
 
 namespace {
@@ -25,24 +25,6 @@ constexpr int KC_BYTES = 128 * 128;       // k-contiguous image
 constexpr int KM_BYTES = 64 * KM_STRIDE;  // k-major image
 constexpr int EP_LD = 132;                // fp32 epilogue tile leading dim (floats)
 
-struct GemmParams {
-    const bf16_t* A;
-    const bf16_t* B;
-    void* C;
-    int64_t lda, ldb, ldc;
-    int M, N, K;
-    const float* bias;
-    const float* gate;
-    int64_t ldg;
-    int rows_per_batch;
-    const float* residual;
-    int64_t ldr;
-    int accumulate;
-    int tiles_n;
-    float alpha;
-    int c_rpb, c_brows, c_roff;
-    const uint8_t* row_mask;
-};
 
 // ---- staging: global -> registers ------------------------------------------------------------
 template <bool KM>
@@ -133,12 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous
-    // run of tiles so neighbours reuse the same A row-panel / B panels from L2. Bijective for any grid.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    int tm, tn;
+    gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[4][4];
@@ -275,53 +253,20 @@ int launch(const GemmParams& p, hipStream_t st) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int tiles_m = (p.M + BM - 1) / BM;
-    dim3 grid(tiles_m * p.tiles_n), block(256);
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
     KALLE_LAUNCH((gemm_bf16_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
 
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 }  // namespace
 
-extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
-                               void* C, int64_t ldc, int c_dtype, int M, int N, int K,
-                               const kalle_gemm_epilogue* ep, void* stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return KALLE_ERR_ARG;
-    if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7)) return KALLE_ERR_ARG;
-    if (!a_kmajor && (K & 7)) return KALLE_ERR_ARG;
-    if (!b_kmajor && (K & 7)) return KALLE_ERR_ARG;
-    if (a_kmajor && (M & 7)) return KALLE_ERR_ARG;
-    if (!al16(A) || !al16(B) || !al16(C)) return KALLE_ERR_ARG;
-    if (c_dtype != KALLE_BF16 && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
-    GemmParams p{};
-    p.A = static_cast<const bf16_t*>(A);
-    p.B = static_cast<const bf16_t*>(B);
-    p.C = C;
-    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.M = M; p.N = N; p.K = K;
-    p.alpha = 1.f;
-    if (ep) {
-        p.bias = ep->bias;
-        p.gate = ep->gate; p.ldg = ep->ldg; p.rows_per_batch = ep->rows_per_batch > 0 ? ep->rows_per_batch : 1;
-        p.residual = ep->residual; p.ldr = ep->ldr;
-        p.accumulate = ep->accumulate;
-        if (ep->alpha != 0.f) p.alpha = ep->alpha;
-        p.row_mask = ep->row_mask;
-        p.c_rpb = ep->c_rows_per_batch; p.c_brows = ep->c_batch_rows; p.c_roff = ep->c_row_offset;
-        if (p.accumulate && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
-        if ((p.bias && !al16(p.bias)) || (p.gate && (!al16(p.gate) || (p.ldg & 3))) ||
-            (p.residual && (!al16(p.residual) || (p.ldr & 3))))
-            return KALLE_ERR_ARG;
-    } else {
-        p.rows_per_batch = 1;
-    }
-    p.tiles_n = (N + BN - 1) / BN;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool f32 = c_dtype == KALLE_F32;
-    if (!a_kmajor && !b_kmajor) return f32 ? launch<false, false, true>(p, st) : launch<false, false, false>(p, st);
-    if (!a_kmajor && b_kmajor) return f32 ? launch<false, true, true>(p, st) : launch<false, true, false>(p, st);
-    if (a_kmajor && !b_kmajor) return f32 ? launch<true, false, true>(p, st) : launch<true, false, false>(p, st);
+int kalle_gemm_v1_launch(const GemmParams& pin, bool a_km, bool b_km, bool f32, hipStream_t st) {
+    GemmParams p = pin;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.group_m = p.tiles_m < 8 ? p.tiles_m : 8;
+    if (!a_km && !b_km) return f32 ? launch<false, false, true>(p, st) : launch<false, false, false>(p, st);
+    if (!a_km && b_km) return f32 ? launch<false, true, true>(p, st) : launch<false, true, false>(p, st);
+    if (a_km && !b_km) return f32 ? launch<true, false, true>(p, st) : launch<true, false, false>(p, st);
     return f32 ? launch<true, true, true>(p, st) : launch<true, true, false>(p, st);
 }

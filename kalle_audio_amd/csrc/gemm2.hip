@@ -1,0 +1,421 @@
+// gemm2: the large-shape bf16 MFMA GEMM (gfx950) + the C-ABI dispatcher kalle_gemm_bf16.
+//
+// 8 waves (512 threads) per workgroup, one workgroup per CU, tile (WM*TM*16) x (WN*64) x 64 with 64x64 or 128x64
+// per wave; operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging); a ring of three LDS stages
+// keeps the DMA of two K-tiles in flight across every barrier (counted vmcnt, never drained);
+// fragments for the NEXT 32-deep k-step are read into a second register set while the MFMAs of the current k-step
+// issue, so LDS latency, the once-per-K-tile barrier and the DMA of the tile after next are all covered by matrix
+// work.  LDS images are lane-linear (an LDS-DMA wave-instruction writes 1 KiB contiguously), so the bank-conflict
+// swizzles are applied to the per-lane SOURCE address and undone by the same involution on the fragment read:
+//   k-contiguous operand [R][64]: 16-B chunk c of row r stored at slot c ^ ((r>>1)&7)            (ds_read_b128)
+//   k-major operand [64][R]:      k-row k stored at position pos(k) (odd 8-blocks: rows 0-3 <-> 4-7), chunk c of
+//                                 position p at slot c ^ (2*(p&7))                                (ds_read_b64_tr_b16)
+// Split-K (wgrad: the output is weight-shaped, the contraction runs over all tokens) turns the grid into
+// tiles x splits with fp32 atomics into a zeroed C - this is what fills 256 CUs when the output has < 256 tiles.
+// Requirements: K % 64 == 0 (otherwise the dispatcher uses the 128x128 kernel of gemm.hip).
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "gemm_common.h"
+#include "../../include/kalle_hip.h"
+
+namespace {
+
+constexpr int BK2 = 64;
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- LDS-DMA issue for one operand region -------------------------------------------------------------------------
+// R: tile extent (rows of a k-contiguous operand / contiguous extent of a k-major one); NW waves share R/8 1-KiB pieces
+template <bool KM, int R, int NW>
+struct Loader {
+    static constexpr int PER_WAVE = (R / 8) / NW;   // 1-KiB wave-instructions per wave per K-tile
+    const bf16_t* src[PER_WAVE];                    // per-lane source pointer of each piece at the current K-tile
+    int64_t kstep;                                  // elements to advance per K-tile
+
+    __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int Rtot, int r0, int k0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int q = wave * PER_WAVE + i;
+            if constexpr (!KM) {
+                const int row = 8 * q + (lane >> 3);
+                const int slot = lane & 7;
+                const int c = slot ^ ((row >> 1) & 7);
+                const int gr = min(r0 + row, Rtot - 1);                     // clamp: rows >= Rtot are never stored
+                src[i] = X + (int64_t)gr * ld + k0 + 8 * c;
+            } else {
+                constexpr int RB = 2 * R;                                   // bytes per k-row
+                constexpr int ROWS = 1024 / RB;                             // k-rows per piece
+                const int pos = q * ROWS + (lane * 16) / RB;
+                const int slot = ((lane * 16) % RB) / 16;
+                const int c = slot ^ (2 * (pos & 7));
+                const int krow = (pos & ~7) | ((pos & 7) ^ (((pos >> 3) & 1) << 2));
+                const int gc = min(r0 + 8 * c, Rtot - 8);
+                src[i] = X + (int64_t)(k0 + krow) * ld + gc;
+            }
+        }
+        kstep = KM ? 64 * ld : 64;
+    }
+    __device__ __forceinline__ void issue(char* region, int wave) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            __builtin_amdgcn_global_load_lds(GPTR(src[i]), LDS_PTR(void, region + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
+            src[i] += kstep;
+        }
+    }
+};
+
+// ---- fragment reads: inline asm, counted by hand ----------------------------------------------------------------
+// hipcc (ROCm 7.2) drains the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of every ds_read_tr builtin and, when the
+// loop spans basic blocks, waits lgkmcnt(0) for reads issued a moment ago - both serialise the pipeline.  The reads
+// are therefore issued from asm statements the compiler does not count; the explicit waits below do the counting.
+template <int OFF>
+__device__ __forceinline__ i32x4 lds_b128(unsigned a) {
+    i32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ i32x2 lds_tr(unsigned a) {
+    i32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
+// per-lane LDS byte offsets of an operand's fragments inside one pipeline stage
+template <bool KM, int R>
+struct Reader {
+    unsigned b0[2], b1[2];   // [k-step]; k-contiguous: b0 only. k-major: the two transposed reads of a fragment
+    __device__ __forceinline__ void init(int region_off, int rbase, int lane) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (!KM) {
+                const int row = rbase + (lane & 15);
+                const int c = 4 * s + (lane >> 4);
+                b0[s] = region_off + row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+                b1[s] = 0;
+            } else {
+                constexpr int RB = 2 * R;
+                const int g = lane >> 4, i = lane & 15;
+                const int q = i >> 2, pp = i & 3;
+                const int b = 4 * s + g;
+                const int odd = b & 1;
+                const int pos1 = 8 * b + (odd ? 4 : 0) + q;
+                const int pos2 = 8 * b + (odd ? 0 : 4) + q;
+                const int cl = (rbase >> 3) + (pp >> 1);          // rbase % 64 == 0: tile t adds 2t to bits 1-2
+                const int hb = (pp & 1) * 8;
+                b0[s] = region_off + pos1 * RB + ((cl ^ (2 * (pos1 & 7))) << 4) + hb;
+                b1[s] = region_off + pos2 * RB + ((cl ^ (2 * (pos2 & 7))) << 4) + hb;
+            }
+        }
+    }
+    // fragments of the 4 tiles (16 operand rows each) of k-step S, stage byte offset `so`
+    template <int S>
+    __device__ __forceinline__ void read(unsigned so, i32x4 (&f)[4]) const {
+        if constexpr (!KM) {
+            const unsigned a = b0[S] + so;
+            f[0] = lds_b128<0>(a);
+            f[1] = lds_b128<2048>(a);
+            f[2] = lds_b128<4096>(a);
+            f[3] = lds_b128<6144>(a);
+        } else {
+            const unsigned a0 = b0[S] + so, a1 = b1[S] + so;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // (cl + 2t) ^ 2u == (cl ^ 2u) ^ 2t for cl % 8 == 0 -> the tile index is an XOR on address bits 5-6
+                const i32x2 lo = lds_tr(a0 ^ (t << 5));
+                const i32x2 hi = lds_tr(a1 ^ (t << 5));
+                f[t] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+    }
+};
+
+#define MFMA16(FA, FB)                                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)          \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
+                                                              __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
+
+template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
+    static_assert(TM == 4, "wave tile is 64 x 64");
+    constexpr int TN = 4;
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int tm, tn;
+    gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk_all = p.K / BK2;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nk = min(p.ktiles_per_split, nk_all - kt0);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Loader<A_KM, BM, NW> la;
+    Loader<B_KM, BN, NW> lb;
+    la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
+    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane);
+    const int arow = wm * TM * 16, bcol = wn * TN * 16;
+    Reader<A_KM, BM> ra;
+    Reader<B_KM, BN> rb;
+    ra.init(lds0, arow, lane);
+    rb.init(lds0 + A_BYTES, bcol, lane);
+
+    // prologue: up to three tiles in flight (3-stage ring), wait for tile 0 only
+    constexpr int PT = Loader<A_KM, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;   // DMA pieces per tile per wave
+    la.issue(smem, wave);
+    lb.issue(smem + A_BYTES, wave);
+    if (nk > 1) {
+        la.issue(smem + STAGE, wave);
+        lb.issue(smem + STAGE + A_BYTES, wave);
+    }
+    if (nk > 2) {
+        la.issue(smem + 2 * STAGE, wave);
+        lb.issue(smem + 2 * STAGE + A_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
+    } else if (nk > 1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    i32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    ra.template read<0>(0, fa0);
+    rb.template read<0>(0, fb0);
+
+    unsigned so_cur = 0, so_nxt = STAGE;   // byte offsets of the stage being computed / the next one (ring of 3)
+
+    // one K-tile: ISSUE = start the DMA of tile kt+3, NEXT = a tile kt+1 exists, KEEP = tile kt+2's DMA stays in flight
+    auto iteration = [&](auto issue_c, auto next_c, auto keep_c) {
+        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value, KEEP = decltype(keep_c)::value;
+        // ---- k-step 0: set 0 has landed (reads issued one phase ago); read set 1 while the MFMAs of set 0 issue
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ra.template read<1>(so_cur, fa1);
+        rb.template read<1>(so_cur, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA16(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: my reads of this stage are done; everybody's DMA of tile kt+1 has landed; the DMA of tile
+        //      kt+2 (issued one iteration ago) stays in flight across the barrier: counted vmcnt, never drained
+        if constexpr (KEEP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+3 into it
+            la.issue(smem + so_cur, wave);
+            lb.issue(smem + so_cur + A_BYTES, wave);
+        }
+        // ---- k-step 1: read set 0 of the next tile while the MFMAs of set 1 issue
+        if constexpr (NEXT) {
+            ra.template read<0>(so_nxt, fa0);
+            rb.template read<0>(so_nxt, fb0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA16(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        so_cur = so_nxt;
+        so_nxt = so_nxt + STAGE >= 3 * STAGE ? 0 : so_nxt + STAGE;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 3 < nk; ++kt) iteration(T_{}, T_{}, T_{});
+    if (kt + 2 < nk) { iteration(F_{}, T_{}, T_{}); ++kt; }
+    if (kt + 1 < nk) { iteration(F_{}, T_{}, F_{}); ++kt; }
+    iteration(F_{}, F_{}, F_{});
+
+    // ---- epilogue: per wave, one 16 x 64 fp32 piece at a time through a wave-private LDS patch ----------------------
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all waves are done with the pipeline stages
+    constexpr int PLD = 68;         // floats per patch row (64 + 4 pad)
+    float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PLD);
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) patch[(4 * g + r) * PLD + 16 * nt + li] = acc[mt][nt][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rbase = m0 + arow + 16 * mt;
+        if (p.atomic) {
+            // split-K: 64 consecutive floats of one row per wave-instruction (256 contiguous bytes per atomic)
+            const int gn = n0 + bcol + lane;
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const int gm = rbase + r;
+                if (gm < p.M && gn < p.N)
+                    atomicAdd(reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn, patch[r * PLD + lane] * p.alpha);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = g + 4 * i;
+                const int gm = rbase + r, gn = n0 + bcol + 4 * li;
+                if (gm >= p.M || gn >= p.N) continue;
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + r * PLD + 4 * li);
+                float v[4] = {pv[0], pv[1], pv[2], pv[3]};
+                const int64_t crow = gemm_crow(p, gm);
+                gemm_epilogue4(p, gm, gn, crow, v);
+                if constexpr (C_F32) {
+                    float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
+                    if (p.accumulate) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += c0[j];
+                    }
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    i32x2 o;
+                    o[0] = (int)pack_bf16x2(v[0], v[1]);
+                    o[1] = (int)pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<i32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next piece overwrites it
+    }
+}
+
+template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
+int launch2(const GemmParams& p, hipStream_t st) {
+    constexpr int BM = WM * TM * 16, BN = WN * 64;
+    constexpr int lds = 3 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 64);
+    KALLE_LAUNCH((gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), grid, block, lds, st, p);
+    return kalle_check_launch();
+}
+
+template <int WM, int WN, int TM>
+int launch2_layout(const GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st) {
+    if (!a_km && !b_km) return f32 ? launch2<false, false, true, WM, WN, TM>(p, st) : launch2<false, false, false, WM, WN, TM>(p, st);
+    if (!a_km && b_km) return f32 ? launch2<false, true, true, WM, WN, TM>(p, st) : launch2<false, true, false, WM, WN, TM>(p, st);
+    if (a_km && b_km) return launch2<true, true, true, WM, WN, TM>(p, st);   // wgrad: fp32 out only
+    return KALLE_ERR_UNSUPPORTED;
+}
+
+int g_force = -1;  // KALLE_GEMM=v1 | v2 (A/B testing); default: v2 where eligible
+int force_mode() {
+    if (g_force < 0) {
+        const char* e = getenv("KALLE_GEMM");
+        g_force = !e ? 0 : (!strcmp(e, "v1") ? 1 : (!strcmp(e, "v2") ? 2 : 0));
+    }
+    return g_force;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st) {
+    if (p.K % BK2) return KALLE_ERR_UNSUPPORTED;
+    if (a_km && !b_km) return KALLE_ERR_UNSUPPORTED;
+    if (a_km && !f32) return KALLE_ERR_UNSUPPORTED;
+    if (p.M < 256 || p.N < 128) return KALLE_ERR_UNSUPPORTED;
+    if (a_km && (p.M & 7)) return KALLE_ERR_UNSUPPORTED;
+    constexpr int BM = 256, BN = 128;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / BK2;
+    p.splits = 1;
+    p.atomic = 0;
+    p.group_m = p.tiles_m < 4 ? p.tiles_m : 4;
+    const bool plain = !p.bias && !p.gate && !p.residual && !p.row_mask && p.c_rpb == 0;
+    if (f32 && plain && a_km && nk >= 16) {
+        // wgrad: the output is weight-shaped and may not fill 256 CUs (or fills them unevenly); split the token
+        // contraction when the modelled time (MFMA work / wave-quantisation efficiency + atomic bytes) drops
+        const double work = 2.0 * p.M * p.N * p.K / 800e12;
+        double best = 1e30;
+        int bs = 1;
+        for (int s = 1; s <= 16 && nk / s >= 8; ++s) {
+            const int blocks = tiles * s;
+            const double eff = (double)blocks / (((blocks + 255) / 256) * 256.0);
+            const double t = work / eff + (s > 1 ? (double)s * p.M * p.N * 4.0 / 2.0e12 : 0.0);
+            if (t < best * 0.97) { best = t; bs = s; }
+        }
+        if (bs > 1) {
+            p.splits = bs;
+            p.atomic = 1;
+            if (!p.accumulate) {
+                if (hipMemset2DAsync(p.C, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, st) != hipSuccess)
+                    return KALLE_ERR_LAUNCH;
+            }
+        }
+    }
+    p.ktiles_per_split = (nk + p.splits - 1) / p.splits;
+    p.splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    return launch2_layout<4, 2, 4>(p, a_km, b_km, f32, st);
+}
+
+static thread_local int g_last_plan = 0;
+extern "C" int kalle_gemm_last_plan(void) { return g_last_plan; }
+
+extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+                               void* C, int64_t ldc, int c_dtype, int M, int N, int K,
+                               const kalle_gemm_epilogue* ep, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return KALLE_ERR_ARG;
+    if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 7)) return KALLE_ERR_ARG;
+    if (!a_kmajor && (K & 7)) return KALLE_ERR_ARG;
+    if (!b_kmajor && (K & 7)) return KALLE_ERR_ARG;
+    if (a_kmajor && (M & 7)) return KALLE_ERR_ARG;
+    if (!al16(A) || !al16(B) || !al16(C)) return KALLE_ERR_ARG;
+    if (c_dtype != KALLE_BF16 && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
+    GemmParams p{};
+    p.A = static_cast<const bf16_t*>(A);
+    p.B = static_cast<const bf16_t*>(B);
+    p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = 1.f;
+    p.rows_per_batch = 1;
+    if (ep) {
+        p.bias = ep->bias;
+        p.gate = ep->gate; p.ldg = ep->ldg; p.rows_per_batch = ep->rows_per_batch > 0 ? ep->rows_per_batch : 1;
+        p.residual = ep->residual; p.ldr = ep->ldr;
+        p.accumulate = ep->accumulate;
+        if (ep->alpha != 0.f) p.alpha = ep->alpha;
+        p.row_mask = ep->row_mask;
+        p.c_rpb = ep->c_rows_per_batch; p.c_brows = ep->c_batch_rows; p.c_roff = ep->c_row_offset;
+        if (p.accumulate && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
+        if ((p.bias && !al16(p.bias)) || (p.gate && (!al16(p.gate) || (p.ldg & 3))) ||
+            (p.residual && (!al16(p.residual) || (p.ldr & 3))))
+            return KALLE_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool f32 = c_dtype == KALLE_F32;
+    if (force_mode() != 1) {
+        const int rc = kalle_gemm_v2_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);
+        if (rc != KALLE_ERR_UNSUPPORTED) {
+            g_last_plan = 2 | (p.splits << 8);
+            return rc;
+        }
+        if (force_mode() == 2 && getenv("KALLE_GEMM_STRICT")) return rc;
+    }
+    p.tiles_n = (N + 127) / 128;
+    g_last_plan = 1;
+    return kalle_gemm_v1_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);
+}

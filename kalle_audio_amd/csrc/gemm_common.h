@@ -1,0 +1,74 @@
+// Shared between the two GEMM kernels (gemm.hip: 128x128 register-staged, any shape; gemm2.hip: 256-wide tiles,
+// LDS-DMA pipeline, split-K) - parameter block and the fused epilogue on 4 consecutive output columns.
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    const float* bias;
+    const float* gate;
+    int64_t ldg;
+    int rows_per_batch;
+    const float* residual;
+    int64_t ldr;
+    int accumulate;
+    int tiles_n;
+    float alpha;
+    int c_rpb, c_brows, c_roff;
+    const uint8_t* row_mask;
+    // gemm2 only
+    int tiles_m, splits, ktiles_per_split, atomic, group_m;
+};
+
+// Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a
+// contiguous run of tile ids (bijective for any grid size).  (2) Grouped raster: consecutive ids walk GM tile-rows x
+// n tile-columns column by column, so the ~32-64 tiles an XCD runs concurrently form a GM x (32/GM) patch that shares
+// GM A-panels and 32/GM B-panels through L2 instead of 1 A-panel and 32 B-panels.
+__device__ __forceinline__ void gemm_tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int per_group = gm * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * gm;
+    const int gsz = min(gm, tiles_m - first_m);
+    const int in = wg - group * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
+// logical output row -> stored row (project_in writes behind the prepended tokens of the residual stream)
+__device__ __forceinline__ int64_t gemm_crow(const GemmParams& p, int gm) {
+    return p.c_rpb > 0 ? (int64_t)(gm / p.c_rpb) * p.c_brows + p.c_roff + gm % p.c_rpb : gm;
+}
+
+// v[0..3] = accumulators of row gm, columns gn..gn+3 ; applies alpha, bias, adaLN gate, row mask, residual
+__device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int gm, int gn, int64_t crow, float (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+    if (p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + gn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b[j];
+    }
+    if (p.gate) {  // adaLN gating, transformer.py:667,681: x * sigmoid(1 - gate)
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gate + (int64_t)(gm / p.rows_per_batch) * p.ldg + gn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= sigmoidf_(1.f - g[j]);
+    }
+    if (p.row_mask && !p.row_mask[gm]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = 0.f;
+    }
+    if (p.residual) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + crow * p.ldr + gn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+}
+
+int kalle_gemm_v1_launch(const GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st);
+int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st);  // KALLE_ERR_UNSUPPORTED if n/a

@@ -88,7 +88,9 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
                               M, N, K, ctypes.byref(ep), _stream()), "kalle_gemm_bf16")
     if prof is not None:
         e1.record()
-        variant = "gemm_bf16_kernel<%d,%d,%d>" % (int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32))
+        plan = lib.kalle_gemm_last_plan()
+        variant = "%s<%d,%d,%d>" % ("gemm2_kernel" if (plan & 255) == 2 else "gemm_bf16_kernel", int(a_kmajor),
+                                    int(b_kmajor), int(out.dtype == torch.float32))
         prof.append((variant, 2.0 * M * N * K, e0, e1))
     return out
 

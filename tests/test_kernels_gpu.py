@@ -29,7 +29,9 @@ def _mk(shape, dev, ints=False, seed=0):
     return torch.randn(shape, generator=g).to(dev)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 136, 72), (1008, 384, 192), (77, 24, 16), (256, 512, 1536)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 136, 72), (1008, 384, 192), (77, 24, 16), (256, 512, 1536),
+                                   (1000, 264, 128), (520, 128, 64), (2048, 1024, 640), (256, 128, 4096),
+                                   (768, 384, 2048)])
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_layouts_exact_int(ops, dev, M, N, K, akm, bkm):
     """small-integer operands: products/sums are exact in bf16 x bf16 -> fp32, so any layout / lane-map error shows
@@ -60,8 +62,9 @@ def test_gemm_random_bf16_out(ops, dev, akm, bkm):
     assert rel_l2(out, ref) < 4e-3  # bf16 output rounding only
 
 
-def test_gemm_epilogue(ops, dev):
-    Bt, T, N, K = 3, 40, 136, 72
+@pytest.mark.parametrize("shape", ["small_v1", "large_v2"])
+def test_gemm_epilogue(ops, dev, shape):
+    Bt, T, N, K = (3, 40, 136, 72) if shape == "small_v1" else (4, 126, 384, 256)
     M = Bt * T
     A = _mk((M, K), dev, seed=5).bfloat16()
     W = _mk((N, K), dev, seed=6).bfloat16()
