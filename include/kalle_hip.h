@@ -77,13 +77,14 @@ int kalle_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const fl
 
 /* backward of the above w.r.t. x and gamma/beta.
  *   dx_out = dres + dLN/dx(dy)   (dres: incoming residual-stream gradient fp32 or NULL; may alias dx_out)
+ *   dx_bf16 (optional): the same values rounded to bf16 - the operand of the next dgrad/wgrad GEMMs, saving a cast pass
  *   dgamma_part/dbeta_part: [nparts][D] fp32 partial sums (nparts = value returned by
  *   kalle_layernorm_bwd_parts(rows)); reduce with kalle_colsum_f32.
  */
 int kalle_layernorm_bwd_parts(int rows);
 int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* gamma,
                         const float* scale, int64_t ld_mod, int rows_per_batch,
-                        const float* mean, const float* rstd, const float* dres, float* dx_out,
+                        const float* mean, const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
                         float* dgamma_part, float* dbeta_part, int rows, int D, void* stream);
 
 /* adaLN modulation gradients: dscale[b,d] = sum_t dy*ln, dshift[b,d] = sum_t dy   (transformer.py:665,679) */
@@ -107,8 +108,9 @@ int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out, int rows,
  */
 /* SwiGLU: out[m, j] = h[m, j] * silu(h[m, inner + j])                     (transformer.py:218-219) */
 int kalle_swiglu_fwd(const void* h, void* out, int64_t rows, int inner, void* stream);
-/* dh[m, j] = dout*silu(g), dh[m, inner+j] = dout*x*silu'(g) */
-int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64_t rows, int inner, void* stream);
+/* dh[m, j] = dout*silu(g), dh[m, inner+j] = dout*x*silu'(g);  dbias (optional, fp32 [2*inner]) += column sums of dh
+ * (the GLU projection's bias gradient, fused so dh is not re-read; atomically accumulated - zero it for a fresh sum) */
+int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, float* dbias, int64_t rows, int inner, void* stream);
 /* SiLU on fp32/bf16 vectors (to_cond_embed / to_global_embed / to_scale_shift_gate: dit.py:39-72, transformer.py:641-644) */
 int kalle_silu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int kalle_silu_bwd(const void* dy, const void* x, void* dx, int dtype, int64_t n, void* stream);

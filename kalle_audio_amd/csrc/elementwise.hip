@@ -35,34 +35,54 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
     }
 }
 
+// grid (inner/512, slabs): a thread keeps its 8 columns and walks rows, so the bias-gradient column sums stay in registers
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ h,
-                                                         bf16_t* __restrict__ dh, int64_t rows, int inner) {
-    const int cpr = inner >> 3;
-    const int64_t total = rows * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cpr;
-        const int c = (int)(i - r * cpr) * 8;
-        const i32x4 xv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + c);
-        const i32x4 gv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + inner + c);
-        const i32x4 dv = *reinterpret_cast<const i32x4*>(dout + r * inner + c);
-        i32x4 ox, og;
+                                                         bf16_t* __restrict__ dh, float* __restrict__ dbias,
+                                                         int64_t rows, int inner, int rows_per_slab) {
+    __shared__ float red[4][64 * 16];
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    const int64_t r1 = min(rows, r0 + rows_per_slab);
+    float sx[8], sg[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x[2] = {bf16lo((uint32_t)xv[j]), bf16hi((uint32_t)xv[j])};
-            float g[2] = {bf16lo((uint32_t)gv[j]), bf16hi((uint32_t)gv[j])};
-            float d[2] = {bf16lo((uint32_t)dv[j]), bf16hi((uint32_t)dv[j])};
-            float dx[2], dg[2];
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sg[e] = 0.f; }
+    if (c < inner) {
+        for (int64_t r = r0 + ty; r < r1; r += 4) {
+            const i32x4 xv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + c);
+            const i32x4 gv = *reinterpret_cast<const i32x4*>(h + r * 2 * inner + inner + c);
+            const i32x4 dv = *reinterpret_cast<const i32x4*>(dout + r * inner + c);
+            i32x4 ox, og;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float s = sigmoidf_(g[e]);
-                dx[e] = d[e] * g[e] * s;
-                dg[e] = d[e] * x[e] * s * (1.f + g[e] * (1.f - s));
+            for (int j = 0; j < 4; ++j) {
+                float x[2] = {bf16lo((uint32_t)xv[j]), bf16hi((uint32_t)xv[j])};
+                float g[2] = {bf16lo((uint32_t)gv[j]), bf16hi((uint32_t)gv[j])};
+                float d[2] = {bf16lo((uint32_t)dv[j]), bf16hi((uint32_t)dv[j])};
+                float dx[2], dg[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float sgm = sigmoidf_(g[e]);
+                    dx[e] = d[e] * g[e] * sgm;
+                    dg[e] = d[e] * x[e] * sgm * (1.f + g[e] * (1.f - sgm));
+                }
+                ox[j] = (int)pack_bf16x2(dx[0], dx[1]);
+                og[j] = (int)pack_bf16x2(dg[0], dg[1]);
+                // sum what the wgrad GEMM will see (the bf16-rounded values)
+                sx[2 * j] += bf16lo((uint32_t)ox[j]); sx[2 * j + 1] += bf16hi((uint32_t)ox[j]);
+                sg[2 * j] += bf16lo((uint32_t)og[j]); sg[2 * j + 1] += bf16hi((uint32_t)og[j]);
             }
-            ox[j] = (int)pack_bf16x2(dx[0], dx[1]);
-            og[j] = (int)pack_bf16x2(dg[0], dg[1]);
+            *reinterpret_cast<i32x4*>(dh + r * 2 * inner + c) = ox;
+            *reinterpret_cast<i32x4*>(dh + r * 2 * inner + inner + c) = og;
         }
-        *reinterpret_cast<i32x4*>(dh + r * 2 * inner + c) = ox;
-        *reinterpret_cast<i32x4*>(dh + r * 2 * inner + inner + c) = og;
+    }
+    if (!dbias) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[ty][lane * 16 + e] = sx[e]; red[ty][lane * 16 + 8 + e] = sg[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int l = i >> 4, e = i & 15;
+        const int col = (blockIdx.x * 64 + l) * 8 + (e & 7);
+        if (col < inner) atomicAdd(dbias + (e < 8 ? col : inner + col), red[0][i] + red[1][i] + red[2][i] + red[3][i]);
     }
 }
 
@@ -348,11 +368,18 @@ extern "C" int kalle_swiglu_fwd(const void* h, void* out, int64_t rows, int inne
                        inner);
     return kalle_check_launch();
 }
-extern "C" int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, int64_t rows, int inner, void* stream) {
+extern "C" int kalle_swiglu_bwd(const void* dout, const void* h, void* dh, float* dbias, int64_t rows, int inner,
+                                void* stream) {
     if (!dout || !h || !dh || rows <= 0 || inner <= 0 || (inner & 7)) return KALLE_ERR_ARG;
-    KALLE_LAUNCH(swiglu_bwd_kernel, dim3(grid_for(rows * (inner >> 3), 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(dout),
-                       static_cast<const bf16_t*>(h), static_cast<bf16_t*>(dh), rows, inner);
+    const int gx = (inner + 511) / 512;
+    int slabs = (1536 + gx - 1) / gx;
+    if ((int64_t)slabs * 32 > rows) slabs = (int)((rows + 31) / 32);
+    if (slabs < 1) slabs = 1;
+    const int rps = (int)((rows + slabs - 1) / slabs);
+    slabs = (int)((rows + rps - 1) / rps);
+    KALLE_LAUNCH(swiglu_bwd_kernel, dim3(gx, slabs), dim3(256), 0, static_cast<hipStream_t>(stream),
+                 static_cast<const bf16_t*>(dout), static_cast<const bf16_t*>(h), static_cast<bf16_t*>(dh), dbias, rows,
+                 inner, rps);
     return kalle_check_launch();
 }
 extern "C" int kalle_silu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream) {

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
                                                      int64_t ld_mod, int rpb, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dres, float* dx,
+                                                     bf16_t* __restrict__ dxb,
                                                      float* __restrict__ dgp, float* __restrict__ dbp, int rows, int D) {
     __shared__ float red[4][64 * 8 + 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     for (int e = 0; e < 8; ++e) o[e] += r[e];
                 }
                 store8<true>(dx, (int64_t)row * D + col, o);
+                if (dxb) store8<false>(dxb, (int64_t)row * D + col, o);
             }
         }
     }
@@ -394,7 +396,8 @@ extern "C" int kalle_layernorm_bwd_parts(int rows) {
 
 extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* gamma,
                                    const float* scale, int64_t ld_mod, int rows_per_batch, const float* mean,
-                                   const float* rstd, const float* dres, float* dx_out, float* dgamma_part,
+                                   const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
+                                   float* dgamma_part,
                                    float* dbeta_part, int rows, int D, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx_out || rows <= 0 || (D & 7) || D <= 0 || D > 4096)
         return KALLE_ERR_ARG;
@@ -404,10 +407,12 @@ extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, c
 #define CALL(N)                                                                                                   \
     if (x_dtype == KALLE_F32)                                                                                     \
         KALLE_LAUNCH((ln_bwd_kernel<N, true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma, \
-                           scale, ld_mod, rpb, mean, rstd, dres, dx_out, dgamma_part, dbeta_part, rows, D);       \
+                           scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16), dgamma_part,   \
+                           dbeta_part, rows, D);                                                                   \
     else                                                                                                          \
         KALLE_LAUNCH((ln_bwd_kernel<N, false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,      \
-                           gamma, scale, ld_mod, rpb, mean, rstd, dres, dx_out, dgamma_part, dbeta_part, rows, D);
+                           gamma, scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16),         \
+                           dgamma_part, dbeta_part, rows, D);
     DISPATCH_NCH(D, CALL);
 #undef CALL
     return kalle_check_launch();

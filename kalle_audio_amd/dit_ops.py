@@ -73,13 +73,26 @@ class GradOut:
         else:
             self.grads[name] = ops.colsum(src)
 
-    def ln(self, name, dy, x, gamma, mean, rstd, **kw):
-        """LayerNorm backward: returns dx; dgamma goes to the sink / grads."""
+    def ln(self, name, dy, x, gamma, mean, rstd, want_bf16=False, **kw):
+        """LayerNorm backward: returns (dx fp32, dx bf16 | None); dgamma goes to the sink / grads."""
         s = self._sink(name)
+        dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
         dx, dgamma, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma_out=s.view(-1) if s is not None else None,
-                                          accumulate=self.accumulate if s is not None else False, **kw)
+                                          accumulate=self.accumulate if s is not None else False, dx_bf16=dxb, **kw)
         self.grads[name] = None if s is not None else dgamma
-        return dx
+        return dx, dxb
+
+    def bias_acc(self, name, n, device):
+        """fp32 [n] buffer a kernel atomically ADDS a bias gradient into (zeroed first unless accumulating)."""
+        s = self._sink(name)
+        if s is not None:
+            if not self.accumulate:
+                s.zero_()
+            self.grads[name] = None
+            return s.view(-1)
+        t = torch.zeros(n, device=device, dtype=F32)
+        self.grads[name] = t
+        return t
 
 
 def dgrad(dy, w, **kw):
@@ -165,10 +178,9 @@ def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff."):
     if want_bias:
         go.colsum(pre + "2.bias", gb)
     dact = dgrad(gb, w2)
-    dhf = ops.swiglu_bwd(dact, hf)
+    db1 = go.bias_acc(pre + "0.proj.bias", hf.shape[-1], hf.device) if want_bias else None
+    dhf = ops.swiglu_bwd(dact, hf, db1)           # bias gradient fused: dhf is not re-read for a column sum
     go.wgrad(pre + "0.proj.weight", dhf, h)
-    if want_bias:
-        go.colsum(pre + "0.proj.bias", dhf)
     return dgrad(dhf, w1)
 
 
@@ -245,8 +257,11 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
     return y, sv
 
 
-def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=None, want_dctx=True):
-    """g: fp32 [B*N, D] gradient of the block output.  Returns (dx fp32, dctx fp32|None, dglobal fp32|None, go)."""
+def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=None, want_dctx=True, g_bf16=None,
+              want_dx_bf16=False):
+    """g: fp32 [B*N, D] gradient of the block output (g_bf16: the same values already rounded to bf16, when the
+    producer - the next block's LayerNorm backward - emitted them).  Returns (dx fp32, dctx fp32|None,
+    dglobal fp32|None, go, dx bf16|None)."""
     D = g.shape[-1]
     go = go or GradOut()
     ada = sv.ada
@@ -261,22 +276,23 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         gb, dg = ops.grad_cast(g, B, N, gate=sl(5), x_out=sv.y, x_in=xin_ff)
         dsl(5).copy_(dg)
     else:
-        gb = ops.cast(g, BF16)
+        gb = g_bf16 if g_bf16 is not None else ops.cast(g, BF16)
     dh3 = ff_bwd(go, gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh3, xin_ff, p.g3, p.beta3, sv.mean3, sv.rstd3, B, N)
         dsl(3).copy_(dsc)
         dsl(4).copy_(dsh)
-    g2 = go.ln("ff_norm.gamma", dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3), rows_per_batch=N, dres=g)
+    g2, g2b = go.ln("ff_norm.gamma", dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3), rows_per_batch=N, dres=g,
+                    want_bf16=True)
     # ---- cross-attention branch
     dctx = None
     if sv.has_cross:
-        g2b = ops.cast(g2, BF16)
         dh2, dctx = cross_attn_bwd(go, g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc,
                                    want_dctx)
-        g1 = go.ln("cross_attend_norm.gamma", dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2)
+        g1, g1bf = go.ln("cross_attend_norm.gamma", dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2,
+                         want_bf16=not ada and mask8 is None)
     else:
-        g1 = g2
+        g1, g1bf = g2, g2b
     # ---- self-attention branch:  x1 = x + SA(LN(x)*(1+sc)+sh) * sigmoid(1-gate)   (masked rows contribute 0)
     if ada:
         g1b, dg = ops.grad_cast(g1, B, N, gate=sl(2), x_out=sv.x1, x_in=sv.x, row_mask=mask8)
@@ -284,17 +300,18 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
     elif mask8 is not None:
         g1b, _ = ops.grad_cast(g1, B, N, row_mask=mask8)
     else:
-        g1b = ops.cast(g1, BF16)
+        g1b = g1bf if g1bf is not None else ops.cast(g1, BF16)
     dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
         dsl(0).copy_(dsc)
         dsl(1).copy_(dsh)
-    dx = go.ln("pre_norm.gamma", dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0), rows_per_batch=N, dres=g1)
+    dx, dxb = go.ln("pre_norm.gamma", dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0), rows_per_batch=N, dres=g1,
+                    want_bf16=want_dx_bf16)
     dglobal = None
     if ada:
         dmb = ops.cast(dmod, BF16)
         go.wgrad("to_scale_shift_gate.1.weight", dmb, sv.sgb)
         dsg = dgrad(dmb, p.wmod, out_dtype=F32)
         dglobal = ops.silu_bwd(dsg, sv.x_global)
-    return dx, dctx, dglobal, go
+    return dx, dctx, dglobal, go, dxb

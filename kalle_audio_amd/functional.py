@@ -225,6 +225,15 @@ class SpliceFn(torch.autograd.Function):
         return dpre, dtok.to(tdt)
 
 
+# bf16 shadows of residual-stream gradients handed from block i+1's backward to block i's (keyed by the fp32
+# gradient's address, tagged with the producing layer so a recycled address can never be mistaken for a live one)
+_GRAD_SHADOW = {}
+
+
+def xdt_is_f32(ctx):
+    return ctx.dtypes[0] == F32
+
+
 class TransformerBlockFn(torch.autograd.Function):
     """One fused TransformerBlock (transformer.py:649-695): LN -> self-attn (+RoPE) -> [LN -> cross-attn] -> LN ->
     SwiGLU FF with adaLN modulation/gating and residual adds fused into the GEMM epilogues."""
@@ -258,8 +267,18 @@ class TransformerBlockFn(torch.autograd.Function):
         gf = _to_f32(g.contiguous()).view(B * N, Dm)
         sinks = getattr(blk, "_kalle_grad_sinks", None)
         go = D.GradOut(sinks, getattr(blk, "_kalle_grad_accumulate", False)) if sinks else D.GradOut()
-        dx, dctx, dglobal, go = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
-                                            want_dctx=ctx.needs_input_grad[2])
+        # bf16 copy of the incoming gradient, if the block above (layer_ix + 1) left one for exactly this tensor
+        sh = _GRAD_SHADOW.pop(gf.data_ptr(), None)
+        g_bf16 = None
+        if sh is not None and sh[0] == blk.layer_ix + 1 and sh[1].shape == gf.shape:
+            g_bf16 = sh[1]
+        if len(_GRAD_SHADOW) > 8:
+            _GRAD_SHADOW.clear()
+        dx, dctx, dglobal, go, dxb = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
+                                                 want_dctx=ctx.needs_input_grad[2], g_bf16=g_bf16,
+                                                 want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx))
+        if dxb is not None:
+            _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb)
         gr = go.grads
         ctx.sv = None
         hook = getattr(blk, "_kalle_on_backward_done", None)

@@ -115,8 +115,9 @@ def layernorm_fwd(x, gamma, beta=None, scale=None, shift=None, rows_per_batch=0,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=None, dx_out=None, want_dbeta=False,
-                  dgamma_out=None, accumulate=False):
-    """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None); dgamma_out (+accumulate) writes dgamma in place"""
+                  dgamma_out=None, accumulate=False, dx_bf16=None):
+    """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None); dgamma_out (+accumulate) writes dgamma in place;
+    dx_bf16: optional bf16 tensor that receives a rounded copy of dx"""
     lib = _lib.load()
     rows, D = _rows2d(x)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
@@ -127,7 +128,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=N
         dx_out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     ld_mod = scale.stride(-2) if scale is not None else 0
     check(lib.kalle_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
-                                  _p(rstd), _p(dres), _p(dx_out), _p(dgp), _p(dbp), rows, D, _stream()),
+                                  _p(rstd), _p(dres), _p(dx_out), _p(dx_bf16), _p(dgp), _p(dbp), rows, D, _stream()),
           "kalle_layernorm_bwd")
     dgamma = colsum(dgp, out=dgamma_out, accumulate=accumulate)
     dbeta = colsum(dbp) if want_dbeta else None
@@ -190,11 +191,13 @@ def swiglu_fwd(h):
     return out
 
 
-def swiglu_bwd(dout, h):
+def swiglu_bwd(dout, h, dbias=None):
+    """dbias: optional fp32 [2*inner] that the kernel atomically adds the column sums of dh to"""
     lib = _lib.load()
     rows, two_inner = _rows2d(h)
     dh = torch.empty_like(h)
-    check(lib.kalle_swiglu_bwd(_p(dout), _p(h), _p(dh), rows, two_inner // 2, _stream()), "kalle_swiglu_bwd")
+    check(lib.kalle_swiglu_bwd(_p(dout), _p(h), _p(dh), _p(dbias), rows, two_inner // 2, _stream()),
+          "kalle_swiglu_bwd")
     return dh
 
 

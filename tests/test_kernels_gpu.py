@@ -154,6 +154,9 @@ def test_swiglu_silu(ops, dev):
     o.backward(dout.float())
     assert rel_l2(ops.swiglu_fwd(h), o) < 4e-3
     assert rel_l2(ops.swiglu_bwd(dout, h), hr.grad) < 5e-3
+    db = torch.zeros(256, device=dev)
+    dh = ops.swiglu_bwd(dout, h, db)
+    assert rel_l2(db, dh.float().sum(0)) < 1e-5       # fused bias gradient = column sums of what was written
     x = _mk((1000,), dev, seed=22)
     xr = x.clone().requires_grad_(True)
     F.silu(xr).backward(torch.ones_like(x) * 0.5)
