@@ -24,12 +24,13 @@ constexpr float SM_SCALE = 0.125f;         // 1/sqrt(64)
 constexpr float NEG_BIG = -1.0e30f;
 
 // stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying partial rotary (rot==32)
+template <int NT>
 __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
                                            int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i;
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int id = tid + NT * i;
         const int row = id >> 3, c = id & 7;
         i32x4 v = {0, 0, 0, 0};
         if (row < nvalid) {
@@ -109,7 +110,11 @@ struct AttnParams {
 };
 
 // ================================================================================================ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+// QT = 16-row query tiles per wave: 2 -> 4 waves per workgroup (wave = 32 queries), 1 -> 8 waves (wave = 16 queries,
+// <= 128 VGPRs so two workgroups = 16 waves share a CU and hide each other's load -> LDS -> MFMA latency chain)
+template <int QT>
+__global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fwd_kernel(AttnParams p) {
+    constexpr int NT = 128 / (16 * QT) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* Ks = smem + AT_TILE;
@@ -125,26 +130,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const bf16_t* ksrc = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
     const bf16_t* vsrc = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
 
-    stage_tile(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid);
+    stage_tile<NT>(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid);
     __syncthreads();
-    bf16x8 qf[2][2];
+    bf16x8 qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qf[qt][s] = rowfrag(Qs, wave * 32 + 16 * qt, s, lane);
+        for (int s = 0; s < 2; ++s) qf[qt][s] = rowfrag(Qs, wave * (16 * QT) + 16 * qt, s, lane);
 
-    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
-    f32x4 o[4][2];
+    float m[QT], l[QT];
+    f32x4 o[4][QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m[qt] = NEG_BIG; l[qt] = 0.f; }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int k0 = 0; k0 < p.Nk; k0 += 128) {
         __syncthreads();  // previous block's K/V reads are done
         const int kval = min(128, p.Nk - k0);
-        stage_tile(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
-        stage_tile(Vs, vsrc, p.ldv, k0, kval, nullptr, nullptr, 0, tid);
+        stage_tile<NT>(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
+        stage_tile<NT>(Vs, vsrc, p.ldv, k0, kval, nullptr, nullptr, 0, tid);
         if (tid < 128) {
             float bias = 0.f;
             if (tid >= kval) bias = -INFINITY;                                           // padding: never attended
@@ -153,25 +160,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         }
         __syncthreads();
 
-        f32x4 acc[8][2];
+        f32x4 acc[8][QT];
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
-            acc[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
-                acc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][s], acc[kt][0], 0, 0, 0);
-                acc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][s], acc[kt][1], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], acc[kt][qt], 0, 0, 0);
             }
         }
         // scale, mask, online softmax (query = lane&15 column; keys on rows 4g+reg of each key tile)
-        float mx[2] = {NEG_BIG, NEG_BIG};
+        float mx[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mx[qt] = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) {
             const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float sv = acc[kt][qt][r] * SM_SCALE;
@@ -180,9 +190,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                     mx[qt] = fmaxf(mx[qt], sv);
                 }
         }
-        float alpha[2];
+        float alpha[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const float mn = fmaxf(m[qt], xor16_32_max(mx[qt]));
             alpha[qt] = __expf(m[qt] - mn);
             m[qt] = mn;
@@ -204,22 +214,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         // O^T += V^T P^T
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 pb0 = pack_pair(acc[2 * ks][0], acc[2 * ks + 1][0]);
-            const bf16x8 pb1 = pack_pair(acc[2 * ks][1], acc[2 * ks + 1][1]);
+            bf16x8 pb[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) pb[qt] = pack_pair(acc[2 * ks][qt], acc[2 * ks + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const bf16x8 vf = trfrag(Vs, 32 * ks, 32 * ks + 16, 16 * dt, lane);
-                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb0, o[dt][0], 0, 0, 0);
-                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb1, o[dt][1], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[qt], o[dt][qt], 0, 0, 0);
             }
         }
     }
 
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const float lt = xor16_32_sum(l[qt]);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        const int qi = q0 + wave * 32 + 16 * qt + li;
+        const int qi = q0 + wave * (16 * QT) + 16 * qt + li;
         if (qi < p.Nq) {
             bf16_t* op = p.out + ((int64_t)b * p.Nq + qi) * p.ldo + h * 64 + 4 * g;
 #pragma unroll
@@ -269,8 +281,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 //           S^T[key,q] = K Q^T ; dQ^T += K^T dS^T
 // In both, the owner's fragments sit in registers (B operand, "column" index on the lane) and the streamed tensors
 // are LDS images read as row fragments (A operand) and as transposed fragments.
-template <bool KV>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
+template <bool KV, int OT>
+__global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bwd_kernel(AttnParams p) {
+    constexpr int NT = 128 / (16 * OT) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* R1 = smem;
     char* R2 = smem + AT_TILE;
@@ -291,29 +304,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     // ---- owner fragments -> registers ----
     if constexpr (KV) {
         const int val = min(128, p.Nk - o0);
-        stage_tile(R1, kbase, p.ldk, o0, val, p.cosT, p.sinT, p.rot, tid);
-        stage_tile(R2, vbase, p.ldv, o0, val, nullptr, nullptr, 0, tid);
+        stage_tile<NT>(R1, kbase, p.ldk, o0, val, p.cosT, p.sinT, p.rot, tid);
+        stage_tile<NT>(R2, vbase, p.ldv, o0, val, nullptr, nullptr, 0, tid);
     } else {
         const int val = min(128, p.Nq - o0);
         const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hown * 64;
         const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hown * 64;
-        stage_tile(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid);
-        stage_tile(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
+        stage_tile<NT>(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid);
+        stage_tile<NT>(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
     }
     __syncthreads();
-    bf16x8 y1[2][2], y2[2][2];
+    bf16x8 y1[OT][2], y2[OT][2];
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
+    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            y1[ot][s] = rowfrag(R1, wave * 32 + 16 * ot, s, lane);
-            y2[ot][s] = rowfrag(R2, wave * 32 + 16 * ot, s, lane);
+            y1[ot][s] = rowfrag(R1, wave * (16 * OT) + 16 * ot, s, lane);
+            y2[ot][s] = rowfrag(R2, wave * (16 * OT) + 16 * ot, s, lane);
         }
     // per-owner-column scalars
-    float ca[2], cb[2];  // KV: ca = key valid (1/0). !KV: ca = lse[q], cb = delta[q]
+    float ca[OT], cb[OT];  // KV: ca = key valid (1/0). !KV: ca = lse[q], cb = delta[q]
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-        const int oi = o0 + wave * 32 + 16 * ot + li;
+    for (int ot = 0; ot < OT; ++ot) {
+        const int oi = o0 + wave * (16 * OT) + 16 * ot + li;
         if constexpr (KV) {
             bool ok = oi < p.Nk;
             if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + oi] != 0;
@@ -326,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
         }
     }
 
-    f32x4 g1[4][2], g2[4][2];  // g2: dK^T / dQ^T accumulators [d tile][owner tile]; g1: dV^T (KV only)
+    f32x4 g1[4][OT], g2[4][OT];  // g2: dK^T / dQ^T accumulators [d tile][owner tile]; g1: dV^T (KV only)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
+        for (int ot = 0; ot < OT; ++ot) {
             g1[dt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
             g2[dt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -345,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
             if constexpr (KV) {
                 const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hq * 64;
                 const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hq * 64;
-                stage_tile(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid);
-                stage_tile(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
+                stage_tile<NT>(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                stage_tile<NT>(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
                 if (tid < 128) {
                     const bool ok = tid < sval;
                     const int64_t idx = ((int64_t)b * p.H + hq) * p.Nq + s0 + tid;
@@ -354,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
                     rowb[tid] = ok ? p.delta[idx] : 0.f;
                 }
             } else {
-                stage_tile(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
-                stage_tile(R2, vbase, p.ldv, s0, sval, nullptr, nullptr, 0, tid);
+                stage_tile<NT>(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                stage_tile<NT>(R2, vbase, p.ldv, s0, sval, nullptr, nullptr, 0, tid);
                 if (tid < 128) {
                     bool ok = tid < sval;
                     if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + s0 + tid] != 0;
@@ -366,12 +379,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
 
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
-                f32x4 sa[2][2], dp[2][2];  // [streamed tile of the pair][owner tile]
+                f32x4 sa[2][OT], dp[2][OT];  // [streamed tile of the pair][owner tile]
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int rb = 32 * pr + 16 * t;
 #pragma unroll
-                    for (int ot = 0; ot < 2; ++ot) {
+                    for (int ot = 0; ot < OT; ++ot) {
                         sa[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
                         dp[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
                         const bf16x8 x1 = rowfrag(R1, rb, s, lane);
                         const bf16x8 x2 = rowfrag(R2, rb, s, lane);
 #pragma unroll
-                        for (int ot = 0; ot < 2; ++ot) {
+                        for (int ot = 0; ot < OT; ++ot) {
                             sa[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, y1[ot][s], sa[t][ot], 0, 0, 0);
                             dp[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, y2[ot][s], dp[t][ot], 0, 0, 0);
                         }
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
                     f32x4 rbv = f32x4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (KV) rbv = *reinterpret_cast<const f32x4*>(rowb + rb + 4 * g);
 #pragma unroll
-                    for (int ot = 0; ot < 2; ++ot)
+                    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float pv, dl;
@@ -405,9 +418,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
                             dp[t][ot][r] = pv * (dp[t][ot][r] - dl) * SM_SCALE;
                         }
                 }
-                bf16x8 pb[2], dsb[2];
+                bf16x8 pb[OT], dsb[OT];
 #pragma unroll
-                for (int ot = 0; ot < 2; ++ot) {
+                for (int ot = 0; ot < OT; ++ot) {
                     pb[ot] = pack_pair(sa[0][ot], sa[1][ot]);
                     dsb[ot] = pack_pair(dp[0][ot], dp[1][ot]);
                 }
@@ -415,12 +428,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
                 for (int dt = 0; dt < 4; ++dt) {
                     const bf16x8 a1 = trfrag(R1, 32 * pr, 32 * pr + 16, 16 * dt, lane);
 #pragma unroll
-                    for (int ot = 0; ot < 2; ++ot)
+                    for (int ot = 0; ot < OT; ++ot)
                         g2[dt][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, dsb[ot], g2[dt][ot], 0, 0, 0);
                     if constexpr (KV) {
                         const bf16x8 a2 = trfrag(R2, 32 * pr, 32 * pr + 16, 16 * dt, lane);
 #pragma unroll
-                        for (int ot = 0; ot < 2; ++ot)
+                        for (int ot = 0; ot < OT; ++ot)
                             g1[dt][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, pb[ot], g1[dt][ot], 0, 0, 0);
                     }
                 }
@@ -431,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnParams p) {
     // ---- epilogue: un-rotate (transpose of the rotary map) and store; lane holds d = 16dt + 4g + r for its column
     const int nown = KV ? p.Nk : p.Nq;
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-        const int oi = o0 + wave * 32 + 16 * ot + li;
+    for (int ot = 0; ot < OT; ++ot) {
+        const int oi = o0 + wave * (16 * OT) + 16 * ot + li;
         if (oi >= nown) continue;
         if (p.rot) {
             const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * 16 + 4 * g);
@@ -499,11 +512,11 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
     constexpr int lds = 3 * AT_TILE + 128 * 4;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    dim3 grid((Nq + 127) / 128, H, B), block(256);
-    KALLE_LAUNCH(attn_fwd_kernel, grid, block, lds, static_cast<hipStream_t>(stream), p);
+    dim3 grid((Nq + 127) / 128, H, B), block(512);
+    KALLE_LAUNCH(attn_fwd_kernel<1>, grid, block, lds, static_cast<hipStream_t>(stream), p);
     return kalle_check_launch();
 }
 
@@ -533,13 +546,13 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     constexpr int lds = 2 * AT_TILE + 256 * 4;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    KALLE_LAUNCH((attn_bwd_kernel<true>), dim3((Nk + 127) / 128, Hkv, B), dim3(256), lds, st, p);
-    KALLE_LAUNCH((attn_bwd_kernel<false>), dim3((Nq + 127) / 128, H, B), dim3(256), lds, st, p);
+    KALLE_LAUNCH((attn_bwd_kernel<true, 1>), dim3((Nk + 127) / 128, Hkv, B), dim3(512), lds, st, p);
+    KALLE_LAUNCH((attn_bwd_kernel<false, 1>), dim3((Nq + 127) / 128, H, B), dim3(512), lds, st, p);
     return kalle_check_launch();
 }

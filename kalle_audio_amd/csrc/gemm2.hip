@@ -110,18 +110,24 @@ struct Reader {
         }
     }
     // fragments of the 4 tiles (16 operand rows each) of k-step S, stage byte offset `so`
-    template <int S>
-    __device__ __forceinline__ void read(unsigned so, i32x4 (&f)[4]) const {
+    template <int S, int NTILE>
+    __device__ __forceinline__ void read(unsigned so, i32x4 (&f)[NTILE]) const {
         if constexpr (!KM) {
             const unsigned a = b0[S] + so;
             f[0] = lds_b128<0>(a);
             f[1] = lds_b128<2048>(a);
             f[2] = lds_b128<4096>(a);
             f[3] = lds_b128<6144>(a);
+            if constexpr (NTILE == 8) {
+                f[4] = lds_b128<8192>(a);
+                f[5] = lds_b128<10240>(a);
+                f[6] = lds_b128<12288>(a);
+                f[7] = lds_b128<14336>(a);
+            }
         } else {
             const unsigned a0 = b0[S] + so, a1 = b1[S] + so;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < NTILE; ++t) {
                 // (cl + 2t) ^ 2u == (cl ^ 2u) ^ 2t for cl % 8 == 0 -> the tile index is an XOR on address bits 5-6
                 const i32x2 lo = lds_tr(a0 ^ (t << 5));
                 const i32x2 hi = lds_tr(a1 ^ (t << 5));
@@ -130,6 +136,62 @@ struct Reader {
         }
     }
 };
+
+// ---- epilogue: per wave, one 16 x 64 fp32 piece at a time through a wave-private LDS patch ---------------------------
+template <bool C_F32, int TM>
+__device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane,
+                                              int row0, int col0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all waves are done with the pipeline stages
+    constexpr int PLD = 68;         // floats per patch row (64 + 4 pad)
+    float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PLD);
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) patch[(4 * g + r) * PLD + 16 * nt + li] = acc[mt][nt][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rbase = row0 + 16 * mt;
+        if (p.atomic) {
+            // split-K: 64 consecutive floats of one row per wave-instruction (256 contiguous bytes per atomic)
+            const int gn = col0 + lane;
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const int gm = rbase + r;
+                if (gm < p.M && gn < p.N)
+                    atomicAdd(reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn, patch[r * PLD + lane] * p.alpha);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = g + 4 * i;
+                const int gm = rbase + r, gn = col0 + 4 * li;
+                if (gm >= p.M || gn >= p.N) continue;
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + r * PLD + 4 * li);
+                float v[4] = {pv[0], pv[1], pv[2], pv[3]};
+                const int64_t crow = gemm_crow(p, gm);
+                gemm_epilogue4(p, gm, gn, crow, v);
+                if constexpr (C_F32) {
+                    float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
+                    if (p.accumulate) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += c0[j];
+                    }
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    i32x2 o;
+                    o[0] = (int)pack_bf16x2(v[0], v[1]);
+                    o[1] = (int)pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<i32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next piece overwrites it
+    }
+}
 
 #define MFMA16(FA, FB)                                                                                         \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)          \
@@ -195,8 +257,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
 
     i32x4 fa0[4], fb0[4], fa1[4], fb1[4];
-    ra.template read<0>(0, fa0);
-    rb.template read<0>(0, fb0);
+    ra.template read<0, 4>(0, fa0);
+    rb.template read<0, 4>(0, fb0);
 
     unsigned so_cur = 0, so_nxt = STAGE;   // byte offsets of the stage being computed / the next one (ring of 3)
 
@@ -206,8 +268,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
         // ---- k-step 0: set 0 has landed (reads issued one phase ago); read set 1 while the MFMAs of set 0 issue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        ra.template read<1>(so_cur, fa1);
-        rb.template read<1>(so_cur, fb1);
+        ra.template read<1, 4>(so_cur, fa1);
+        rb.template read<1, 4>(so_cur, fb1);
         __builtin_amdgcn_sched_barrier(0);
         MFMA16(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -230,8 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
         }
         // ---- k-step 1: read set 0 of the next tile while the MFMAs of set 1 issue
         if constexpr (NEXT) {
-            ra.template read<0>(so_nxt, fa0);
-            rb.template read<0>(so_nxt, fb0);
+            ra.template read<0, 4>(so_nxt, fa0);
+            rb.template read<0, 4>(so_nxt, fb0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (wave < NW / 2) {
@@ -250,57 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     if (kt + 1 < nk) { iteration(F_{}, T_{}, F_{}); ++kt; }
     iteration(F_{}, F_{}, F_{});
 
-    // ---- epilogue: per wave, one 16 x 64 fp32 piece at a time through a wave-private LDS patch ----------------------
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // all waves are done with the pipeline stages
-    constexpr int PLD = 68;         // floats per patch row (64 + 4 pad)
-    float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PLD);
-    const int g = lane >> 4, li = lane & 15;
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) patch[(4 * g + r) * PLD + 16 * nt + li] = acc[mt][nt][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int rbase = m0 + arow + 16 * mt;
-        if (p.atomic) {
-            // split-K: 64 consecutive floats of one row per wave-instruction (256 contiguous bytes per atomic)
-            const int gn = n0 + bcol + lane;
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const int gm = rbase + r;
-                if (gm < p.M && gn < p.N)
-                    atomicAdd(reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn, patch[r * PLD + lane] * p.alpha);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = g + 4 * i;
-                const int gm = rbase + r, gn = n0 + bcol + 4 * li;
-                if (gm >= p.M || gn >= p.N) continue;
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + r * PLD + 4 * li);
-                float v[4] = {pv[0], pv[1], pv[2], pv[3]};
-                const int64_t crow = gemm_crow(p, gm);
-                gemm_epilogue4(p, gm, gn, crow, v);
-                if constexpr (C_F32) {
-                    float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
-                    if (p.accumulate) {
-                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += c0[j];
-                    }
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    i32x2 o;
-                    o[0] = (int)pack_bf16x2(v[0], v[1]);
-                    o[1] = (int)pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<i32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next piece overwrites it
-    }
+    wave_epilogue<C_F32, TM>(p, acc, smem, wave, lane, m0 + arow, n0 + bcol);
 }
 
 template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
@@ -316,6 +328,137 @@ int launch2(const GemmParams& p, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 64);
     KALLE_LAUNCH((gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), grid, block, lds, st, p);
     return kalle_check_launch();
+}
+
+
+// ================================================================================================ 256 x 256 tile
+// 8 waves as 2 (M) x 4 (N), 128 x 64 per wave (128 accumulator VGPRs), two 64-KiB LDS stages, ONE fragment set:
+// a wave reads the 12 fragments of a 32-deep k-step, waits, issues its 32 MFMAs; latency is covered by its SIMD
+// partner, which runs half a phase apart (second half of the workgroup defers the last MFMA block of a K-tile past
+// the barrier).  Per MFMA this tile needs 25 % fewer LDS reads, 33 % fewer DMA pieces and L2->LDS bytes than 256x128.
+#define MFMA32(FA, FB)                                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)          \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
+                                                              __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
+
+template <bool A_KM, bool B_KM, bool C_F32>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
+    constexpr int WN = 4, TM = 8, NW = 8;
+    constexpr int BM = 256, BN = 256;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int tm, tn;
+    gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all = p.K / BK2;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nk = min(p.ktiles_per_split, nk_all - kt0);
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Loader<A_KM, BM, NW> la;
+    Loader<B_KM, BN, NW> lb;
+    la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
+    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane);
+    const int arow = wm * 128, bcol = wn * 64;
+    Reader<A_KM, BM> ra;
+    Reader<B_KM, BN> rb;
+    ra.init(lds0, arow, lane);
+    rb.init(lds0 + A_BYTES, bcol, lane);
+
+    la.issue(smem, wave);
+    lb.issue(smem + A_BYTES, wave);
+    if (nk > 1) {
+        la.issue(smem + STAGE, wave);
+        lb.issue(smem + STAGE + A_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 + 4 DMA pieces per tile per wave
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    i32x4 fa[8], fb[4];
+    unsigned so_cur = 0;
+    const bool late = wave >= NW / 2;     // the staggered half
+    // prologue of the software pipeline: k-step 0 of tile 0
+    ra.template read<0, 8>(0, fa);
+    rb.template read<0, 4>(0, fb);
+
+    auto iteration = [&](auto issue_c, auto next_c) {
+        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+        // k-step 0 of this tile is in flight / landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA32(fa, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        ra.template read<1, 8>(so_cur, fa);
+        rb.template read<1, 4>(so_cur, fb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last reads of this stage are done
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) {
+            MFMA32(fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // hand-over: everybody's DMA of tile kt+1 has landed, everybody is done reading this stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) {
+            MFMA32(fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+2 into it
+            la.issue(smem + so_cur, wave);
+            lb.issue(smem + so_cur + A_BYTES, wave);
+        }
+        so_cur ^= STAGE;
+        if constexpr (NEXT) {
+            ra.template read<0, 8>(so_cur, fa);
+            rb.template read<0, 4>(so_cur, fb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 2 < nk; ++kt) iteration(T_{}, T_{});
+    if (kt + 1 < nk) { iteration(F_{}, T_{}); ++kt; }
+    iteration(F_{}, F_{});
+
+    wave_epilogue<C_F32, TM>(p, acc, smem, wave, lane, m0 + arow, n0 + bcol);
+}
+
+template <bool A_KM, bool B_KM, bool C_F32>
+int launch3(const GemmParams& p, hipStream_t st) {
+    constexpr int lds = 2 * (256 + 256) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
+    KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
+    return kalle_check_launch();
+}
+
+int launch3_layout(const GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st) {
+    if (!a_km && !b_km) return f32 ? launch3<false, false, true>(p, st) : launch3<false, false, false>(p, st);
+    if (!a_km && b_km) return f32 ? launch3<false, true, true>(p, st) : launch3<false, true, false>(p, st);
+    if (a_km && b_km) return launch3<true, true, true>(p, st);
+    return KALLE_ERR_UNSUPPORTED;
 }
 
 template <int WM, int WN, int TM>
@@ -345,38 +488,42 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     if (a_km && !f32) return KALLE_ERR_UNSUPPORTED;
     if (p.M < 256 || p.N < 128) return KALLE_ERR_UNSUPPORTED;
     if (a_km && (p.M & 7)) return KALLE_ERR_UNSUPPORTED;
-    constexpr int BM = 256, BN = 128;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = p.tiles_m * p.tiles_n;
     const int nk = p.K / BK2;
-    p.splits = 1;
-    p.atomic = 0;
-    p.group_m = p.tiles_m < 4 ? p.tiles_m : 4;
     const bool plain = !p.bias && !p.gate && !p.residual && !p.row_mask && p.c_rpb == 0;
-    if (f32 && plain && a_km && nk >= 16) {
-        // wgrad: the output is weight-shaped and may not fill 256 CUs (or fills them unevenly); split the token
-        // contraction when the modelled time (MFMA work / wave-quantisation efficiency + atomic bytes) drops
-        const double work = 2.0 * p.M * p.N * p.K / 800e12;
-        double best = 1e30;
-        int bs = 1;
-        for (int s = 1; s <= 16 && nk / s >= 8; ++s) {
+    const bool can_split = f32 && plain && a_km && nk >= 16;
+    static int tile_env = -1;
+    if (tile_env < 0) {
+        const char* e = getenv("KALLE_GEMM_TILE");
+        tile_env = e ? atoi(e) : 0;
+    }
+    // modelled time of a configuration: MFMA work / (tile rate x wave-quantisation efficiency) + split-K atomic bytes
+    const double flops = 2.0 * p.M * p.N * p.K;
+    double best = 1e30;
+    int best_bn = 128, best_s = 1;
+    for (int bn = 128; bn <= 256; bn += 128) {
+        if (tile_env && bn != tile_env) continue;
+        if (bn == 256 && p.N < 256) continue;
+        const double rate = bn == 256 ? 1150e12 : 1000e12;
+        const int tiles = ((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
+        for (int s = 1; s <= (can_split ? 16 : 1) && (s == 1 || nk / s >= 8); ++s) {
             const int blocks = tiles * s;
             const double eff = (double)blocks / (((blocks + 255) / 256) * 256.0);
-            const double t = work / eff + (s > 1 ? (double)s * p.M * p.N * 4.0 / 2.0e12 : 0.0);
-            if (t < best * 0.97) { best = t; bs = s; }
+            const double t = flops / (rate * eff) + (s > 1 ? (double)s * p.M * p.N * 4.0 / 2.0e12 : 0.0);
+            if (t < best * 0.98) { best = t; best_bn = bn; best_s = s; }
         }
-        if (bs > 1) {
-            p.splits = bs;
-            p.atomic = 1;
-            if (!p.accumulate) {
-                if (hipMemset2DAsync(p.C, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, st) != hipSuccess)
-                    return KALLE_ERR_LAUNCH;
-            }
-        }
+    }
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + best_bn - 1) / best_bn;
+    p.group_m = p.tiles_m < 4 ? p.tiles_m : 4;
+    p.splits = best_s;
+    p.atomic = best_s > 1;
+    if (p.atomic && !p.accumulate) {
+        if (hipMemset2DAsync(p.C, p.ldc * sizeof(float), 0, p.N * sizeof(float), p.M, st) != hipSuccess)
+            return KALLE_ERR_LAUNCH;
     }
     p.ktiles_per_split = (nk + p.splits - 1) / p.splits;
     p.splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    if (best_bn == 256) return launch3_layout(p, a_km, b_km, f32, st);
     return launch2_layout<4, 2, 4>(p, a_km, b_km, f32, st);
 }
 
