@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-depth", type=int, default=None, help="time a shallower oracle and scale (debug)")
@@ -181,13 +181,14 @@ def main():
         }
         if timer:
             agg = {}
-            for variant, fl, e0, e1 in timer:
-                a = agg.setdefault(variant, [0.0, 0.0, 0])
+            for variant, fl, e0, e1, ab in timer:
+                a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
                 a[0] += fl
                 a[1] += e0.elapsed_time(e1) * 1e-3
                 a[2] += 1
+                a[3] += ab
             dom = max(agg.items(), key=lambda kv: kv[1][1])
-            name, (fl, sec, n) = dom
+            name, (fl, sec, n, ab) = dom
             ach = fl / sec / 1e12
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -196,6 +197,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                                "launches": n, "avg_launch_us": sec / n * 1e6, "avg_flop_per_launch": fl / n,
+                               "algorithmic_bytes_per_launch": ab / n,
                                "all_gemm_variants": {k: {"tflops": v[0] / v[1] / 1e12, "avg_us": v[1] / v[2] * 1e6,
                                                          "launches": v[2], "time_share_of_step":
                                                              v[1] / dt} for k, v in agg.items()}}

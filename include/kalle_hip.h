@@ -62,7 +62,8 @@ int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int
                     const kalle_gemm_epilogue* ep, void* stream);
 
 /* which kernel the calling thread's most recent kalle_gemm_bf16 used: low byte 1 = gemm_bf16_kernel (128x128,
- * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 64 == 0); bits 8.. = split-K factor */
+ * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 64 == 0), 3 = gemm3_kernel (256x256, 2 stages); bits 8.. =
+ * split-K factor */
 int kalle_gemm_last_plan(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -514,7 +514,11 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     }
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + best_bn - 1) / best_bn;
-    p.group_m = p.tiles_m < 4 ? p.tiles_m : 4;
+    p.tile_n = best_bn;
+    static int gm_env = -1;
+    if (gm_env < 0) { const char* e = getenv("KALLE_GEMM_GM"); gm_env = e ? atoi(e) : 0; }
+    const int gm_want = gm_env > 0 ? gm_env : 4;
+    p.group_m = p.tiles_m < gm_want ? p.tiles_m : gm_want;
     p.splits = best_s;
     p.atomic = best_s > 1;
     if (p.atomic && !p.accumulate) {
@@ -566,7 +570,7 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
     if (force_mode() != 1) {
         const int rc = kalle_gemm_v2_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);
         if (rc != KALLE_ERR_UNSUPPORTED) {
-            g_last_plan = 2 | (p.splits << 8);
+            g_last_plan = (p.tile_n == 256 ? 3 : 2) | (p.splits << 8);
             return rc;
         }
         if (force_mode() == 2 && getenv("KALLE_GEMM_STRICT")) return rc;

@@ -21,7 +21,7 @@ struct GemmParams {
     int c_rpb, c_brows, c_roff;
     const uint8_t* row_mask;
     // gemm2 only
-    int tiles_m, splits, ktiles_per_split, atomic, group_m;
+    int tiles_m, splits, ktiles_per_split, atomic, group_m, tile_n;
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a

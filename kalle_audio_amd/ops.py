@@ -89,9 +89,10 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     if prof is not None:
         e1.record()
         plan = lib.kalle_gemm_last_plan()
-        variant = "%s<%d,%d,%d>" % ("gemm2_kernel" if (plan & 255) == 2 else "gemm_bf16_kernel", int(a_kmajor),
-                                    int(b_kmajor), int(out.dtype == torch.float32))
-        prof.append((variant, 2.0 * M * N * K, e0, e1))
+        kname = {1: "gemm_bf16_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(plan & 255, "gemm")
+        variant = "%s<%d,%d,%d>" % (kname, int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32))
+        abytes = 2.0 * (M * K + N * K) + M * N * out.element_size() + (4.0 * M * N if residual is not None else 0.0)
+        prof.append((variant, 2.0 * M * N * K, e0, e1, abytes))
     return out
 
 
