@@ -55,6 +55,16 @@ typedef struct kalle_gemm_epilogue {
     int32_t c_row_offset;
     const uint8_t* row_mask; /* [M] or NULL: rows with 0 contribute 0 before the residual add
                               * (Attention zeroes padded query rows after to_out, transformer.py:543-545) */
+    /* fused SwiGLU (transformer.py:216-219), bf16 C, 256x256 kernel only (returns KALLE_ERR_UNSUPPORTED otherwise -
+     * the caller then runs the GEMM and kalle_swiglu_* separately):
+     *   glu_mode 1 (forward,  a_kmajor=0,b_kmajor=0, N = 2*glu_inner): C = h = x W^T + b  [M][2*inner]  AND
+     *              glu_aux = act [M][inner] bf16 = h[:, j] * silu(h[:, inner + j])
+     *   glu_mode 2 (backward, a_kmajor=0,b_kmajor=1, N = glu_inner):   acc = d(act); glu_aux = h [M][2*inner] bf16;
+     *              C = dh [M][2*inner] bf16; glu_dbias (fp32 [2*inner], optional) += column sums of dh */
+    int32_t glu_mode;
+    int32_t glu_inner;
+    void* glu_aux;
+    float* glu_dbias;
 } kalle_gemm_epilogue;
 
 int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,

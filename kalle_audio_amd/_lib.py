@@ -36,6 +36,10 @@ class GemmEpilogue(ctypes.Structure):
         ("c_batch_rows", ctypes.c_int32),
         ("c_row_offset", ctypes.c_int32),
         ("row_mask", ctypes.c_void_p),
+        ("glu_mode", ctypes.c_int32),
+        ("glu_inner", ctypes.c_int32),
+        ("glu_aux", ctypes.c_void_p),
+        ("glu_dbias", ctypes.c_void_p),
     ]
 
 

@@ -34,7 +34,10 @@ struct Loader {
     const bf16_t* src[PER_WAVE];                    // per-lane source pointer of each piece at the current K-tile
     int64_t kstep;                                  // elements to advance per K-tile
 
-    __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int Rtot, int r0, int k0, int wave, int lane) {
+    // glu_inner > 0 (k-contiguous B of the fused SwiGLU forward): the 256 tile rows are, per 64-row wave slice,
+    // 32 rows of the x half followed by the 32 matching rows of the gate half of the [2*inner][K] GLU weight
+    __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int Rtot, int r0, int k0, int wave, int lane,
+                                         int glu_inner = 0, int glu_tn = 0) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int q = wave * PER_WAVE + i;
@@ -42,7 +45,11 @@ struct Loader {
                 const int row = 8 * q + (lane >> 3);
                 const int slot = lane & 7;
                 const int c = slot ^ ((row >> 1) & 7);
-                const int gr = min(r0 + row, Rtot - 1);                     // clamp: rows >= Rtot are never stored
+                int gr = min(r0 + row, Rtot - 1);                           // clamp: rows >= Rtot are never stored
+                if (glu_inner > 0) {
+                    const int wn_ = row >> 6, w_ = row & 63;
+                    gr = (w_ >= 32 ? glu_inner : 0) + glu_tn * 128 + wn_ * 32 + (w_ & 31);
+                }
                 src[i] = X + (int64_t)gr * ld + k0 + 8 * c;
             } else {
                 constexpr int RB = 2 * R;                                   // bytes per k-row
@@ -138,7 +145,7 @@ struct Reader {
 };
 
 // ---- epilogue: per wave, one 16 x 64 fp32 piece at a time through a wave-private LDS patch ---------------------------
-template <bool C_F32, int TM>
+template <bool C_F32, int TM, int GLU = 0>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane,
                                               int row0, int col0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -146,6 +153,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
     constexpr int PLD = 68;         // floats per patch row (64 + 4 pad)
     float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PLD);
     const int g = lane >> 4, li = lane & 15;
+    float sx[8], sg[8];             // GLU backward: bias-gradient partial sums of this lane's 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sg[e] = 0.f; }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
@@ -154,7 +164,70 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             for (int r = 0; r < 4; ++r) patch[(4 * g + r) * PLD + 16 * nt + li] = acc[mt][nt][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rbase = row0 + 16 * mt;
-        if (p.atomic) {
+        if constexpr (GLU == 1) {
+            // fused SwiGLU forward (transformer.py:216-219): patch cols 0-31 = x, 32-63 = gate of act columns col0..+31
+            const int r = lane >> 2, c8 = (lane & 3) * 8;
+            const int gm = rbase + r, j0 = col0 + c8;
+            if (gm < p.M && j0 < p.glu_inner) {
+                float xv[8], gv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[e] = patch[r * PLD + c8 + e]; gv[e] = patch[r * PLD + 32 + c8 + e]; }
+                if (p.bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { xv[e] += p.bias[j0 + e]; gv[e] += p.bias[p.glu_inner + j0 + e]; }
+                }
+                i32x4 hx, hg, av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hx[e] = (int)pack_bf16x2(xv[2 * e], xv[2 * e + 1]);
+                    hg[e] = (int)pack_bf16x2(gv[2 * e], gv[2 * e + 1]);
+                    // activation from the bf16-rounded pre-activation, exactly what the unfused kernel would read back
+                    const float x0 = bf16lo((uint32_t)hx[e]), x1 = bf16hi((uint32_t)hx[e]);
+                    const float g0 = bf16lo((uint32_t)hg[e]), g1 = bf16hi((uint32_t)hg[e]);
+                    av[e] = (int)pack_bf16x2(x0 * siluf_(g0), x1 * siluf_(g1));
+                }
+                bf16_t* hp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
+                *reinterpret_cast<i32x4*>(hp + j0) = hx;
+                *reinterpret_cast<i32x4*>(hp + p.glu_inner + j0) = hg;
+                *reinterpret_cast<i32x4*>(static_cast<bf16_t*>(p.glu_aux) + (int64_t)gm * p.glu_inner + j0) = av;
+            }
+        } else if constexpr (GLU == 2) {
+            // fused SwiGLU backward: acc = d(act)[m][j]; reads h, writes dh = (dact*silu(g), dact*x*silu'(g)), sums db
+            const int c8 = (lane & 7) * 8, j0 = col0 + c8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = (lane >> 3) + 8 * half;
+                const int gm = rbase + r;
+                if (gm < p.M && j0 < p.glu_inner) {
+                    const bf16_t* hp = static_cast<const bf16_t*>(p.glu_aux) + (int64_t)gm * 2 * p.glu_inner;
+                    const i32x4 xv = *reinterpret_cast<const i32x4*>(hp + j0);
+                    const i32x4 gv = *reinterpret_cast<const i32x4*>(hp + p.glu_inner + j0);
+                    i32x4 ox, og;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x[2] = {bf16lo((uint32_t)xv[e]), bf16hi((uint32_t)xv[e])};
+                        const float gg[2] = {bf16lo((uint32_t)gv[e]), bf16hi((uint32_t)gv[e])};
+                        // the unfused path rounds dact to bf16 between the GEMM and the activation backward
+                        const float d[2] = {bf16_to_f32(f32_to_bf16(patch[r * PLD + c8 + 2 * e] * p.alpha)),
+                                            bf16_to_f32(f32_to_bf16(patch[r * PLD + c8 + 2 * e + 1] * p.alpha))};
+                        float dx[2], dg[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float sgm = sigmoidf_(gg[q]);
+                            dx[q] = d[q] * gg[q] * sgm;
+                            dg[q] = d[q] * x[q] * sgm * (1.f + gg[q] * (1.f - sgm));
+                        }
+                        ox[e] = (int)pack_bf16x2(dx[0], dx[1]);
+                        og[e] = (int)pack_bf16x2(dg[0], dg[1]);
+                        sx[2 * e] += bf16lo((uint32_t)ox[e]); sx[2 * e + 1] += bf16hi((uint32_t)ox[e]);
+                        sg[2 * e] += bf16lo((uint32_t)og[e]); sg[2 * e + 1] += bf16hi((uint32_t)og[e]);
+                    }
+                    bf16_t* dp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
+                    *reinterpret_cast<i32x4*>(dp + j0) = ox;
+                    *reinterpret_cast<i32x4*>(dp + p.glu_inner + j0) = og;
+                }
+            }
+        } else if (p.atomic) {
             // split-K: 64 consecutive floats of one row per wave-instruction (256 contiguous bytes per atomic)
             const int gn = col0 + lane;
 #pragma unroll 4
@@ -190,6 +263,24 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next piece overwrites it
+    }
+    if constexpr (GLU == 2) {
+        if (p.glu_dbias) {
+            // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row-lanes, then 16 atomics from lanes 0-7
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { sx[e] += __shfl_xor(sx[e], o, 64); sg[e] += __shfl_xor(sg[e], o, 64); }
+            }
+            const int j0 = col0 + (lane & 7) * 8;
+            if (lane < 8 && j0 < p.glu_inner) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(p.glu_dbias + j0 + e, sx[e]);
+                    atomicAdd(p.glu_dbias + p.glu_inner + j0 + e, sg[e]);
+                }
+            }
+        }
     }
 }
 
@@ -341,7 +432,7 @@ int launch2(const GemmParams& p, hipStream_t st) {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
                                                               __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
 
-template <bool A_KM, bool B_KM, bool C_F32>
+template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     constexpr int WN = 4, TM = 8, NW = 8;
     constexpr int BM = 256, BN = 256;
@@ -369,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     Loader<A_KM, BM, NW> la;
     Loader<B_KM, BN, NW> lb;
     la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
-    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane);
+    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
     const int arow = wm * 128, bcol = wn * 64;
     Reader<A_KM, BM> ra;
     Reader<B_KM, BN> rb;
@@ -437,20 +528,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     if (kt + 1 < nk) { iteration(F_{}, T_{}); ++kt; }
     iteration(F_{}, F_{});
 
-    wave_epilogue<C_F32, TM>(p, acc, smem, wave, lane, m0 + arow, n0 + bcol);
+    wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wave, lane, m0 + arow, GLU == 1 ? tn * 128 + wn * 32 : n0 + bcol);
 }
 
-template <bool A_KM, bool B_KM, bool C_F32>
+template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
 int launch3(const GemmParams& p, hipStream_t st) {
     constexpr int lds = 2 * (256 + 256) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32, GLU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
-    KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
+    KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32, GLU>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
 
@@ -489,6 +580,22 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     if (p.M < 256 || p.N < 128) return KALLE_ERR_UNSUPPORTED;
     if (a_km && (p.M & 7)) return KALLE_ERR_UNSUPPORTED;
     const int nk = p.K / BK2;
+    if (p.glu_mode) {
+        // fused SwiGLU: 256 x 256 kernel only; forward pairs x/gate weight rows inside each wave's 64 tile columns
+        if (a_km || f32 || p.gate || p.residual || p.row_mask || p.c_rpb || p.accumulate) return KALLE_ERR_UNSUPPORTED;
+        if (p.glu_inner % 128 || p.N != (p.glu_mode == 1 ? 2 * p.glu_inner : p.glu_inner)) return KALLE_ERR_UNSUPPORTED;
+        if (p.glu_mode == 1 && b_km) return KALLE_ERR_UNSUPPORTED;
+        if (p.glu_mode == 2 && (!b_km || p.bias)) return KALLE_ERR_UNSUPPORTED;
+        p.tiles_m = (p.M + 255) / 256;
+        p.tiles_n = p.glu_mode == 1 ? p.glu_inner / 128 : (p.glu_inner + 255) / 256;
+        p.tile_n = 256;
+        p.group_m = p.tiles_m < 4 ? p.tiles_m : 4;
+        p.splits = 1;
+        p.atomic = 0;
+        p.ktiles_per_split = nk;
+        if (p.glu_mode == 1) return launch3<false, false, false, 1>(p, st);
+        return launch3<false, true, false, 2>(p, st);
+    }
     const bool plain = !p.bias && !p.gate && !p.residual && !p.row_mask && p.c_rpb == 0;
     const bool can_split = f32 && plain && a_km && nk >= 16;
     static int tile_env = -1;
@@ -560,6 +667,8 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
         if (ep->alpha != 0.f) p.alpha = ep->alpha;
         p.row_mask = ep->row_mask;
         p.c_rpb = ep->c_rows_per_batch; p.c_brows = ep->c_batch_rows; p.c_roff = ep->c_row_offset;
+        p.glu_mode = ep->glu_mode; p.glu_inner = ep->glu_inner; p.glu_aux = ep->glu_aux; p.glu_dbias = ep->glu_dbias;
+        if (p.glu_mode && (!p.glu_aux || p.glu_inner <= 0)) return KALLE_ERR_ARG;
         if (p.accumulate && c_dtype != KALLE_F32) return KALLE_ERR_ARG;
         if ((p.bias && !al16(p.bias)) || (p.gate && (!al16(p.gate) || (p.ldg & 3))) ||
             (p.residual && (!al16(p.residual) || (p.ldr & 3))))
@@ -575,6 +684,7 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
         }
         if (force_mode() == 2 && getenv("KALLE_GEMM_STRICT")) return rc;
     }
+    if (p.glu_mode) return KALLE_ERR_UNSUPPORTED;   // fused SwiGLU exists only in the 256x256 kernel: caller un-fuses
     p.tiles_n = (N + 127) / 128;
     g_last_plan = 1;
     return kalle_gemm_v1_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);

@@ -22,6 +22,11 @@ struct GemmParams {
     const uint8_t* row_mask;
     // gemm2 only
     int tiles_m, splits, ktiles_per_split, atomic, group_m, tile_n;
+    // fused SwiGLU (gemm3 only): 1 = forward (C = h [M][2*inner], glu_aux = act [M][inner]); 2 = backward (acc = dact,
+    // glu_aux = h, C = dh [M][2*inner], glu_dbias += column sums of dh)
+    int glu_mode, glu_inner;
+    void* glu_aux;
+    float* glu_dbias;
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a

@@ -166,8 +166,12 @@ def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_
 # ------------------------------------------------------------------------------------------------ feed-forward
 def ff_fwd(h, w1, b1, w2, b2, N, residual=None, gate=None, out_dtype=F32):
     """transformer.py:216-219 (GLU proj + x*silu(gate)), 252 (linear_out)."""
-    hf = ops.gemm(h, w1, bias=b1)
-    act = ops.swiglu_fwd(hf)
+    M, inner = h.shape[0], w1.shape[0] // 2
+    hf = torch.empty((M, 2 * inner), device=h.device, dtype=BF16)
+    act = torch.empty((M, inner), device=h.device, dtype=BF16)
+    if ops.gemm(h, w1, bias=b1, out=hf, glu_mode=1, glu_inner=inner, glu_aux=act) is None:   # fused GEMM + SwiGLU
+        ops.gemm(h, w1, bias=b1, out=hf)
+        act = ops.swiglu_fwd(hf)
     out = ops.gemm(act, w2, bias=b2, out_dtype=out_dtype, residual=residual, gate=gate, rows_per_batch=N)
     return out, (hf, act)
 
@@ -177,9 +181,13 @@ def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff."):
     go.wgrad(pre + "2.weight", gb, act)
     if want_bias:
         go.colsum(pre + "2.bias", gb)
-    dact = dgrad(gb, w2)
     db1 = go.bias_acc(pre + "0.proj.bias", hf.shape[-1], hf.device) if want_bias else None
-    dhf = ops.swiglu_bwd(dact, hf, db1)           # bias gradient fused: dhf is not re-read for a column sum
+    dhf = torch.empty_like(hf)
+    # dgrad GEMM with the SwiGLU backward and the GLU bias gradient fused into its epilogue (d(act) never hits HBM)
+    if ops.gemm(gb, w2, b_kmajor=True, out=dhf, N=hf.shape[-1] // 2, glu_mode=2, glu_inner=hf.shape[-1] // 2,
+                glu_aux=hf, glu_dbias=db1) is None:
+        dact = dgrad(gb, w2)
+        dhf = ops.swiglu_bwd(dact, hf, db1)
     go.wgrad(pre + "0.proj.weight", dhf, h)
     return dgrad(dhf, w1)
 

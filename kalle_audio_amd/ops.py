@@ -41,7 +41,8 @@ def _rows2d(t):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bfloat16, M=None, N=None, K=None,
          lda=None, ldb=None, ldc=None, bias=None, gate=None, rows_per_batch=0, residual=None, accumulate=False,
-         alpha=1.0, c_rows_per_batch=0, c_batch_rows=0, c_row_offset=0, row_mask=None):
+         alpha=1.0, c_rows_per_batch=0, c_batch_rows=0, c_row_offset=0, row_mask=None, glu_mode=0, glu_inner=0,
+         glu_aux=None, glu_dbias=None):
     """C = op(a) @ op(b) with the fused epilogue of kalle_gemm_bf16.
 
     a: [M,K] (or [K,M] when a_kmajor), b: [N,K] (or [K,N] when b_kmajor); both bf16, last dim contiguous.
@@ -73,6 +74,9 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     ep.alpha = alpha
     ep.c_rows_per_batch, ep.c_batch_rows, ep.c_row_offset = c_rows_per_batch, c_batch_rows, c_row_offset
     ep.row_mask = row_mask.data_ptr() if row_mask is not None else None
+    ep.glu_mode, ep.glu_inner = glu_mode, glu_inner
+    ep.glu_aux = glu_aux.data_ptr() if glu_aux is not None else None
+    ep.glu_dbias = glu_dbias.data_ptr() if glu_dbias is not None else None
     if bias is not None:
         assert bias.dtype == torch.float32
     if gate is not None:
@@ -84,8 +88,11 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.kalle_gemm_bf16(_p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc, _dt(out),
-                              M, N, K, ctypes.byref(ep), _stream()), "kalle_gemm_bf16")
+    rc = lib.kalle_gemm_bf16(_p(a), lda, int(a_kmajor), _p(b), ldb, int(b_kmajor), _p(out), ldc, _dt(out),
+                             M, N, K, ctypes.byref(ep), _stream())
+    if rc == -3 and glu_mode:
+        return None          # fused SwiGLU not available for this shape: the caller runs the unfused sequence
+    check(rc, "kalle_gemm_bf16")
     if prof is not None:
         e1.record()
         plan = lib.kalle_gemm_last_plan()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.kalle_abi_version() == 1
     lib.kalle_target_arch.restype = ctypes.c_char_p
     assert lib.kalle_target_arch() == b"gfx950"
-    assert ctypes.sizeof(_lib.GemmEpilogue) == 80  # matches the C struct layout (checked against hipcc's sizeof)
+    assert ctypes.sizeof(_lib.GemmEpilogue) == 104  # matches the C struct layout (checked against hipcc's sizeof)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
