@@ -220,18 +220,29 @@ int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                            int transposed, void* stream);
 /* y = conv1d(act(x), w, b, stride, padding, dilation) (+ residual) (-> tanh)
- *   act: 0 none, 1 SnakeBeta (act_alpha/act_beta per input channel, exp() applied when act_logscale), 2 ELU
+ *   `padding` is the LEFT zero pad; the right pad is implied by Lout (symmetric padding: autoencoders.py:45,76;
+ *   causal left-only padding: backup/flows.py:574-575,602-603).
+ *   act: 0 none, 1 SnakeBeta (act_alpha/act_beta per input channel, exp() applied when act_logscale; Snake = pass
+ *   alpha as beta too), 2 ELU, 3 LeakyReLU(negative_slope = act_param) (backup/flows.py:177-181,217,230),
+ *   4 WaveNet gate tanh(x[:, :Cin]) * sigmoid(x[:, Cin:]) - x then has 2*Cin channels (backup/flows.py:614-620)
  *   (autoencoders.py:39-62 ResidualUnit, 64-81 EncoderBlock, 116-191 encoder/decoder stems; blocks.py:301-339)
- *   post: 0 none, 1 tanh (autoencoders.py:185).  ksize <= 16. */
+ *   y = (conv + bias + residual) * out_scale, then post bits: 1 tanh (autoencoders.py:185), 2 add the previous contents
+ *   of y first (sum over the parallel AMP blocks, backup/flows.py:517-523).  ksize <= 16. */
 int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, const void* residual,
                      void* y, int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
                      int padding, int dilation, int act, const float* act_alpha, const float* act_beta,
-                     int act_logscale, int post, void* stream);
-/* y = conv_transpose1d(act(x), w, b, stride, padding), ksize <= 2*stride+1   (autoencoders.py:98-100 DecoderBlock) */
+                     int act_logscale, float act_param, float out_scale, int post, void* stream);
+/* y = conv_transpose1d(act(x), w, b, stride, padding), ksize <= 2*stride+1   (autoencoders.py:98-100 DecoderBlock);
+ * Lout may be shorter than the full length: the causal variant trims the last `stride` outputs (backup/flows.py:383-384) */
 int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
                                int padding, int act, const float* act_alpha, const float* act_beta,
-                               int act_logscale, void* stream);
+                               int act_logscale, float act_param, void* stream);
+/* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
+ * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)
+ * -> 2x FIR low-pass downsample.  x, y: (B, C, L) fp32 or bf16; filter12: the 12 fp32 taps. */
+int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* filter12, const float* alpha, const float* beta,
+                    int logscale, int B, int C, int L, void* stream);
 /* standalone SnakeBeta: y = x + sin^2(x e^alpha) / (e^beta + 1e-9)     (blocks.py:301-339) */
 int kalle_snake_beta_fwd(const void* x, void* y, int dtype, const float* alpha, const float* beta, int logscale,
                          int B, int C, int L, void* stream);

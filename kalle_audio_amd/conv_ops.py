@@ -23,31 +23,42 @@ def weight_norm_fold(v, g, transposed=False):
 
 
 def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0, alpha=None, beta=None,
-           logscale=True, residual=None, post=0, out_dtype=None):
+           logscale=True, residual=None, post=0, out_dtype=None, pad_right=None, act_param=0.0, out_scale=1.0,
+           accumulate_into=None):
+    """padding = left pad; pad_right defaults to the same (symmetric). act: 0 none, 1 snake(-beta), 2 ELU, 3 LeakyReLU"""
     lib = _lib.load()
     x = x.contiguous()
     B, Cin, Lin = x.shape
-    Lout = (Lin + 2 * padding - dilation * (K - 1) - 1) // stride + 1
-    y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
+    if act == 4:
+        Cin //= 2
+    pr = padding if pad_right is None else pad_right
+    Lout = (Lin + padding + pr - dilation * (K - 1) - 1) // stride + 1
+    if accumulate_into is not None:
+        y = accumulate_into
+        assert y.is_contiguous() and tuple(y.shape) == (B, Cout, Lout)
+        post |= 2
+    else:
+        y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
     if residual is not None:
         residual = residual.contiguous()
         assert residual.dtype == x.dtype and residual.shape == y.shape
     check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(residual), _p(y), _dt(y), B, Cin, Lin, Cout,
-                               Lout, K, stride, padding, dilation, act, _p(alpha), _p(beta), int(logscale), post,
+                               Lout, K, stride, padding, dilation, act, _p(alpha), _p(beta), int(logscale), act_param, out_scale, post,
                                _stream()), "kalle_conv1d_fwd")
     return y
 
 
 def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alpha=None, beta=None, logscale=True,
-                     out_dtype=None):
+                     out_dtype=None, trim=0, act_param=0.0):
+    """trim: drop the last `trim` outputs (causal transposed conv)"""
     lib = _lib.load()
     x = x.contiguous()
     B, Cin, Lin = x.shape
-    Lout = (Lin - 1) * stride - 2 * padding + K
+    Lout = (Lin - 1) * stride - 2 * padding + K - trim
     y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
     check(lib.kalle_conv_transpose1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout,
                                          Lout, K, stride, padding, act, _p(alpha), _p(beta), int(logscale),
-                                         _stream()), "kalle_conv_transpose1d_fwd")
+                                         act_param, _stream()), "kalle_conv_transpose1d_fwd")
     return y
 
 
@@ -58,4 +69,35 @@ def snake_beta(x, alpha, beta, logscale=True):
     y = torch.empty_like(x)
     check(lib.kalle_snake_beta_fwd(_p(x), _p(y), _dt(x), _p(alpha), _p(beta), int(logscale), B, C, L, _stream()),
           "kalle_snake_beta_fwd")
+    return y
+
+
+def kaiser_sinc_filter12(device, cutoff=0.25, half_width=0.3, kernel_size=12):
+    """the 12-tap low-pass of alias-free-torch's UpSample1d / DownSample1d at ratio 2 (cutoff 0.5/2, half-width 0.6/2):
+    kaiser window (beta from the attenuation implied by the transition width) x sinc, normalised to unit sum."""
+    import math
+    half = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        kb = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        kb = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        kb = 0.0
+    window = torch.kaiser_window(kernel_size, beta=kb, periodic=False, dtype=torch.float64)
+    time = torch.arange(-half, half, dtype=torch.float64) + 0.5
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    filt = filt / filt.sum()
+    return filt.to(device=device, dtype=torch.float32).contiguous()
+
+
+def act1d(x, filt, alpha, beta, logscale):
+    """anti-aliased snake(-beta): up 2x FIR -> activation -> down 2x FIR, one fused kernel"""
+    lib = _lib.load()
+    x = x.contiguous()
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    check(lib.kalle_act1d_fwd(_p(x), _p(y), _dt(x), _p(filt), _p(alpha), _p(beta), int(logscale), B, C, L, _stream()),
+          "kalle_act1d_fwd")
     return y

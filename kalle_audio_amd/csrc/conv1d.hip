@@ -24,6 +24,7 @@ __device__ __forceinline__ float act_apply(float x, int act, float a, float inv_
         return x + inv_b * s * s;
     }
     if (act == 2) return x > 0.f ? x : (__expf(x) - 1.f);  // ELU(alpha=1)
+    if (act == 3) return x > 0.f ? x : x * a;              // LeakyReLU(negative_slope = a)
     return x;
 }
 
@@ -42,6 +43,9 @@ struct ConvParams {
     const void* x; const float* w; const float* bias; const void* res; void* y;
     int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, act, post;
     const float* aa; const float* ab; int logscale;
+    float act_param;
+    float out_scale;
+    int xC;   // channels of the x tensor (2*Cin for the gated activation, else Cin)
 };
 
 template <bool XF32, bool YF32>
@@ -68,13 +72,17 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvParams p) {
             const int ci = ci0 + c, li = in0 + sp;
             float v = 0.f;
             if (ci < p.Cin && li >= 0 && li < p.Lin) {
-                v = ld1<XF32>(p.x, ((int64_t)b * p.Cin + ci) * p.Lin + li);
+                const int64_t xi = ((int64_t)b * p.xC + ci) * p.Lin + li;
+                v = ld1<XF32>(p.x, xi);
                 if (p.act == 1) {
                     float a = p.aa[ci], bb = p.ab[ci];
                     if (p.logscale) { a = __expf(a); bb = __expf(bb); }
                     v = act_apply(v, 1, a, 1.f / (bb + 1e-9f));
-                } else if (p.act == 2) {
-                    v = act_apply(v, 2, 0.f, 0.f);
+                } else if (p.act == 4) {  // WaveNet gate: tanh(x[ci]) * sigmoid(x[Cin + ci])
+                    const float gt = ld1<XF32>(p.x, xi + (int64_t)p.Cin * p.Lin);
+                    v = tanhf(v) / (1.f + __expf(-gt));
+                } else if (p.act >= 2) {
+                    v = act_apply(v, p.act, p.act_param, 0.f);
                 }
             }
             Xs[c][sp] = v;
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvParams p) {
             const int64_t oi = ((int64_t)b * p.Cout + co) * p.Lout + l;
             float v = acc[i][j] + bv;
             if (p.res) v += ld1<XF32>(p.res, oi);
-            if (p.post == 1) v = tanhf(v);
+            v *= p.out_scale;
+            if (p.post & 2) v += ld1<YF32>(p.y, oi);   // accumulate into y (sum over parallel AMP blocks)
+            if (p.post & 1) v = tanhf(v);
             st1<YF32>(p.y, oi, v);
         }
     }
@@ -155,8 +165,8 @@ __global__ __launch_bounds__(256) void convT1d_kernel(ConvParams p) {
                     float a = p.aa[ci], bb = p.ab[ci];
                     if (p.logscale) { a = __expf(a); bb = __expf(bb); }
                     v = act_apply(v, 1, a, 1.f / (bb + 1e-9f));
-                } else if (p.act == 2) {
-                    v = act_apply(v, 2, 0.f, 0.f);
+                } else if (p.act >= 2) {
+                    v = act_apply(v, p.act, p.act_param, 0.f);
                 }
             }
             Xs[c][sp] = v;
@@ -243,7 +253,72 @@ __global__ __launch_bounds__(256) void snake_kernel(const void* __restrict__ x, 
     }
 }
 
+// anti-aliased activation (alias-free-torch Activation1d, used by backup/flows.py:266-279,300-313,452-456):
+//   2x kaiser-sinc FIR upsample (12 taps, replicate padding) -> snake / snake-beta -> 2x FIR low-pass downsample.
+// One workgroup = 256 consecutive outputs of one (batch, channel) row; x segment and the activated 2x-rate
+// signal live in LDS, so HBM sees one read and one write per element.
+constexpr int A1_T = 256;
+template <bool F32>
+__global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                    const float* __restrict__ filt, const float* __restrict__ alpha,
+                                                    const float* __restrict__ beta, int logscale, int C, int L) {
+    __shared__ float xs[A1_T + 16];
+    __shared__ float as[2 * A1_T + 16];
+    __shared__ float f[12];
+    const int row = blockIdx.y;                     // b * C + c
+    const int c = row % C;
+    const int t0 = blockIdx.x * A1_T;
+    const int64_t base = (int64_t)row * L;
+    if (threadIdx.x < 12) f[threadIdx.x] = filt[threadIdx.x];
+    // up-sampled index range needed: m in [2*t0 - 5, 2*t0 + 2*A1_T + 6]; x_pad index i in [(m+4+1)/2, (m+15)/2]
+    const int m0 = 2 * t0 - 5;
+    const int i0 = (m0 + 4) / 2 - 1;                // a safe lower bound of x_pad indices used (may be negative)
+    for (int j = threadIdx.x; j < A1_T + 16; j += 256) {
+        const int xi = min(max(i0 + j - 5, 0), L - 1);   // replicate padding: x_pad[i] = x[clamp(i - 5)]
+        xs[j] = ld1<F32>(x, base + xi);
+    }
+    __syncthreads();
+    float a = alpha[c], b = beta[c];
+    if (logscale) { a = __expf(a); b = __expf(b); }
+    const float inv_b = 1.f / (b + 1e-9f);
+    for (int j = threadIdx.x; j < 2 * A1_T + 12; j += 256) {
+        // a_pad[m] = act(u[clamp(m - 5, 0, 2L-1)]) with m = 2*t0 + j  ->  u index n:
+        const int n = min(max(2 * t0 + j - 5, 0), 2 * L - 1);
+        // u[n] = 2 * sum_i x_pad[i] f[n + 15 - 2i],  i = ceil((n+4)/2) .. floor((n+15)/2)
+        const int ilo = (n + 5) >> 1;               // ceil((n+4)/2)
+        float u = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int i = ilo + q;
+            const int tap = n + 15 - 2 * i;
+            if (tap >= 0 && tap < 12) u += xs[i - i0] * f[tap];
+        }
+        u *= 2.f;
+        const float sn = sinf(u * a);
+        as[j] = u + inv_b * sn * sn;
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t < L) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc += f[j] * as[2 * threadIdx.x + j];
+        st1<F32>(y, base + t, acc);
+    }
+}
+
 }  // namespace
+
+extern "C" int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* filter12, const float* alpha,
+                               const float* beta, int logscale, int B, int C, int L, void* stream) {
+    if (!x || !y || !filter12 || !alpha || !beta || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 65535)
+        return KALLE_ERR_ARG;
+    dim3 grid((L + A1_T - 1) / A1_T, B * C), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == KALLE_F32) KALLE_LAUNCH((act1d_kernel<true>), grid, block, 0, st, x, y, filter12, alpha, beta, logscale, C, L);
+    else KALLE_LAUNCH((act1d_kernel<false>), grid, block, 0, st, x, y, filter12, alpha, beta, logscale, C, L);
+    return kalle_check_launch();
+}
 
 extern "C" int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                                       int transposed, void* stream) {
@@ -256,15 +331,17 @@ extern "C" int kalle_weight_norm_fold(const float* v, const float* g, float* w_p
 extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias,
                                 const void* residual, void* y, int y_dtype, int B, int Cin, int Lin, int Cout, int Lout,
                                 int ksize, int stride, int padding, int dilation, int act, const float* act_alpha,
-                                const float* act_beta, int act_logscale, int post, void* stream) {
+                                const float* act_beta, int act_logscale, float act_param, float out_scale, int post,
+                                void* stream) {
     if (!x || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lout <= 0) return KALLE_ERR_ARG;
     if (ksize <= 0 || ksize > MAX_K || stride <= 0 || dilation <= 0 || padding < 0) return KALLE_ERR_ARG;
     if ((L_T - 1) * stride + (ksize - 1) * dilation + 1 > MAX_SPAN) return KALLE_ERR_UNSUPPORTED;
-    if (Lout != (Lin + 2 * padding - dilation * (ksize - 1) - 1) / stride + 1) return KALLE_ERR_ARG;
+    // `padding` is the LEFT pad; the right pad is implied by Lout (symmetric, 'same' or causal alike): taps beyond Lin read 0
+    if ((int64_t)(Lout - 1) * stride - padding >= Lin) return KALLE_ERR_ARG;
     if (act == 1 && (!act_alpha || !act_beta)) return KALLE_ERR_ARG;
     if (B > 65535 || (Cout + CO_T - 1) / CO_T > 65535) return KALLE_ERR_ARG;
     ConvParams p{x, w_packed, bias, residual, y, B, Cin, Lin, Cout, Lout, ksize, stride, padding, dilation, act, post,
-                 act_alpha, act_beta, act_logscale};
+                 act_alpha, act_beta, act_logscale, act_param, out_scale, act == 4 ? 2 * Cin : Cin};
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
@@ -278,15 +355,16 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
 extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                           int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize,
                                           int stride, int padding, int act, const float* act_alpha,
-                                          const float* act_beta, int act_logscale, void* stream) {
+                                          const float* act_beta, int act_logscale, float act_param, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lout <= 0) return KALLE_ERR_ARG;
     if (ksize <= 0 || ksize > MAX_K + 2 || stride <= 0 || padding < 0) return KALLE_ERR_ARG;
     if (ksize > 2 * stride + 1) return KALLE_ERR_UNSUPPORTED;
-    if (Lout != (Lin - 1) * stride - 2 * padding + ksize) return KALLE_ERR_ARG;
+    if (Lout > (Lin - 1) * stride - 2 * padding + ksize) return KALLE_ERR_ARG;   // shorter = causal trim of the tail
     if (act == 1 && (!act_alpha || !act_beta)) return KALLE_ERR_ARG;
     if (B > 65535 || (Cout + CO_T - 1) / CO_T > 65535) return KALLE_ERR_ARG;
+    if (act == 4) return KALLE_ERR_UNSUPPORTED;
     ConvParams p{x, w_packed, bias, nullptr, y, B, Cin, Lin, Cout, Lout, ksize, stride, padding, 1, act, 0,
-                 act_alpha, act_beta, act_logscale};
+                 act_alpha, act_beta, act_logscale, act_param, 1.f, Cin};
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;

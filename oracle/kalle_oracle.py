@@ -481,3 +481,179 @@ def oobleck_decoder_shapes(out_channels, channels, latent_dim, c_mults, strides,
                                   f"{prefix}layers.{j + 1}.")
     s += _act_shapes(f"{prefix}layers.{n + 1}", cm[0] * channels, use_snake)
     return s + _wnconv_shapes(f"{prefix}layers.{n + 2}", out_channels, cm[0] * channels, 7, bias=False)
+
+
+# ---------------------------------------------------------------------------------------------- mel-VAE (backup/flows.py)
+# Parity status: encoder, ResStack, causal Conv1d / ConvTranspose1d, AMP block wiring, flow: PINNED by
+# tests/golden/melvae.npz.  `activation1d` restates the third-party alias-free-torch package (imported with `*` at
+# backup/flows.py:5, not vendored, version unpinned, absent from this container): PARITY UNPINNED for that one
+# function - the decoder fixtures were generated by running the reference's own classes with this restatement
+# standing in for the missing import, so they pin the wiring around it but not its FIR taps.
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    """alias-free-torch filter.py: kaiser-windowed sinc low-pass, unit DC gain (published algorithm; the
+    StyleGAN3-style design: attenuation from the transition width, kaiser beta from the attenuation)."""
+    half = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        kb = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        kb = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        kb = 0.0
+    window = torch.kaiser_window(kernel_size, beta=kb, periodic=False, dtype=torch.float64)
+    if kernel_size % 2 == 0:
+        time = torch.arange(-half, half, dtype=torch.float64) + 0.5
+    else:
+        time = torch.arange(kernel_size, dtype=torch.float64) - half
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    return (filt / filt.sum()).float()
+
+
+def snake(x, alpha, beta=None, logscale=False):
+    """backup/flows.py:51-62 (Snake) / 113-126 (SnakeBeta): x + sin^2(a x) / (b + 1e-9), b = a for Snake."""
+    a = alpha.view(1, -1, 1)
+    b = a if beta is None else beta.view(1, -1, 1)
+    if logscale:
+        a, b = torch.exp(a), torch.exp(b)
+    return x + (1.0 / (b + 1e-9)) * torch.sin(x * a) ** 2
+
+
+def upsample1d_2x(x, filt):
+    """alias-free-torch resample.py UpSample1d(ratio=2): replicate pad 5, depthwise transposed conv stride 2 with the
+    12-tap filter, x2 gain, crop 15 each side."""
+    C = x.shape[1]
+    x = F.pad(x, (5, 5), mode="replicate")
+    x = 2 * F.conv_transpose1d(x, filt.view(1, 1, -1).expand(C, -1, -1), stride=2, groups=C)
+    return x[..., 15:-15]
+
+
+def downsample1d_2x(x, filt):
+    """alias-free-torch resample.py DownSample1d(ratio=2) = LowPassFilter1d(stride=2): replicate pad (5, 6), depthwise
+    conv stride 2."""
+    C = x.shape[1]
+    x = F.pad(x, (5, 6), mode="replicate")
+    return F.conv1d(x, filt.view(1, 1, -1).expand(C, -1, -1), stride=2, groups=C)
+
+
+def activation1d(x, alpha, beta=None, logscale=False):
+    """alias-free-torch act.py Activation1d(up_ratio=2, down_ratio=2, kernel 12): up -> act -> down."""
+    filt = kaiser_sinc_filter1d(0.25, 0.3, 12).to(x.dtype)
+    return downsample1d_2x(snake(upsample1d_2x(x, filt), alpha, beta, logscale), filt)
+
+
+def res_stack(sd, x, nums=6, base=2):
+    """backup/flows.py:172-191: x += conv3(lrelu(conv3_dil(lrelu(x)))), LeakyReLU slope 0.01, dilation base**i"""
+    for i in range(nums):
+        h = F.leaky_relu(x, 0.01)
+        h = F.conv1d(h, wn_weight(sd, f"layers.{i}.1"), sd[f"layers.{i}.1.bias"], dilation=base ** i, padding=base ** i)
+        h = F.leaky_relu(h, 0.01)
+        h = F.conv1d(h, wn_weight(sd, f"layers.{i}.3"), sd[f"layers.{i}.3.bias"], padding=1)
+        x = x + h
+    return x
+
+
+def melvae_encoder(sd, x, down_factors, stacks=6, base=2):
+    """backup/flows.py:194-241 (keys generator.N[.layer]): conv k3 -> lrelu(.2) -> [conv k=2f stride f pad (2f-1)//2 ->
+    ResStack -> lrelu(.2)]* -> conv k3"""
+    x = F.leaky_relu(F.conv1d(x, wn_weight(sd, "generator.0.layer"), sd["generator.0.layer.bias"], padding=1), 0.2)
+    i = 2
+    for f in down_factors:
+        x = F.conv1d(x, wn_weight(sd, f"generator.{i}.layer"), sd[f"generator.{i}.layer.bias"], stride=f,
+                     padding=(2 * f - 1) // 2)
+        x = res_stack(_sub(sd, f"generator.{i + 1}."), x, stacks, base)
+        x = F.leaky_relu(x, 0.2)
+        i += 3
+    return F.conv1d(x, wn_weight(sd, f"generator.{i}.layer"), sd[f"generator.{i}.layer.bias"], padding=1)
+
+
+def flows_conv1d(x, w, b, dilation=1, causal=False):
+    """backup/flows.py:548-605: 'same' padding (k d - d)/2, or causal left padding d (k-1)"""
+    k = w.shape[-1]
+    if causal:
+        return F.conv1d(F.pad(x, (dilation * (k - 1), 0)), w, b, dilation=dilation)
+    return F.conv1d(x, w, b, dilation=dilation, padding=(k * dilation - dilation) // 2)
+
+
+def flows_conv_transpose1d(x, w, b, stride, causal=False):
+    """backup/flows.py:337-387: k == 2*stride; causal: padding 0 and the last `stride` outputs trimmed"""
+    k = w.shape[-1]
+    if causal:
+        return F.conv_transpose1d(x, w, b, stride=stride)[:, :, :-stride]
+    return F.conv_transpose1d(x, w, b, stride=stride, padding=(k - stride) // 2)
+
+
+def _amp_act(sd, pre, x, h):
+    beta = sd[pre + ".act.beta"] if h["activation"] == "snakebeta" else None
+    return activation1d(x, sd[pre + ".act.alpha"], beta, h["snake_logscale"])
+
+
+def amp_block(sd, x, h, dilations):
+    """AMPBlock1 (backup/flows.py:279-288) when h.resblock == '1', else AMPBlock2 (325-331)"""
+    c = h["causal"]
+    if h["resblock"] == "1":
+        for j, d in enumerate(dilations):
+            xt = _amp_act(sd, f"activations.{2 * j}", x, h)
+            xt = flows_conv1d(xt, wn_weight(sd, f"convs1.{j}"), sd[f"convs1.{j}.bias"], d, c)
+            xt = _amp_act(sd, f"activations.{2 * j + 1}", xt, h)
+            x = flows_conv1d(xt, wn_weight(sd, f"convs2.{j}"), sd[f"convs2.{j}.bias"], 1, c) + x
+        return x
+    for j, d in enumerate(dilations):
+        xt = _amp_act(sd, f"activations.{j}", x, h)
+        x = flows_conv1d(xt, wn_weight(sd, f"convs.{j}"), sd[f"convs.{j}.bias"], d, c) + x
+    return x
+
+
+def melvae_decode(sd, z, h):
+    """BigVGANFlowVAE.inference_from_latents after sampling (backup/flows.py:509-529)"""
+    x = flows_conv1d(z, wn_weight(sd, "conv_pre"), sd["conv_pre.bias"], 1, False)
+    nk = len(h["resblock_kernel_sizes"])
+    for i, u in enumerate(h["upsample_rates"]):
+        x = flows_conv_transpose1d(x, wn_weight(sd, f"ups.{i}.0"), sd[f"ups.{i}.0.bias"], u, h["causal"])
+        xs = None
+        for j in range(nk):
+            y = amp_block(_sub(sd, f"resblocks.{i * nk + j}."), x, h, h["resblock_dilation_sizes"][j])
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = _amp_act(sd, "activation_post", x, h)
+    x = flows_conv1d(x, wn_weight(sd, "conv_post"), sd["conv_post.bias"], 1, h["causal"])
+    return torch.tanh(x)
+
+
+def wn_stack(sd, x, n_layers=4, dilation_rate=1, causal=True):
+    """WN (backup/flows.py:659-687) with g=None, mask of ones, no dropout"""
+    H = x.shape[1]
+    out = torch.zeros_like(x)
+    for i in range(n_layers):
+        x_in = flows_conv1d(x, wn_weight(sd, f"in_layers.{i}"), sd[f"in_layers.{i}.bias"], dilation_rate ** i, causal)
+        acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+        rs = flows_conv1d(acts, wn_weight(sd, f"res_skip_layers.{i}"), sd[f"res_skip_layers.{i}.bias"], 1, causal)
+        if i < n_layers - 1:
+            x = x + rs[:, :H]
+            out = out + rs[:, H:]
+        else:
+            out = out + rs
+    return out
+
+
+def residual_coupling_block(sd, x, n_flows=4, n_layers=4, causal=True):
+    """ResidualCouplingBlock forward direction (backup/flows.py:736-751,783-786), mean_only, followed by Flip each"""
+    half = x.shape[1] // 2
+    for f in range(n_flows):
+        p = f"flows.{2 * f}."
+        x0, x1 = x[:, :half], x[:, half:]
+        hdn = flows_conv1d(x0, sd[p + "pre.weight"], sd[p + "pre.bias"], 1, causal)
+        hdn = wn_stack(_sub(sd, p + "enc."), hdn, n_layers, 1, causal)
+        m = flows_conv1d(hdn, sd[p + "post.weight"], sd[p + "post.bias"], 1, causal)
+        x = torch.cat([x0, m + x1], 1)
+        x = torch.flip(x, [1])
+    return x
+
+
+def melvae_forward(sd, wav, eps, h):
+    """BigVGANFlowVAE.forward (backup/flows.py:457-493) with the reparameterisation noise passed in"""
+    enc = melvae_encoder(_sub(sd, "audio_encoder."), wav, h["downsample_rates"])
+    m_q, logs_q = torch.split(enc, h["latent_dim"], dim=1)
+    z = m_q + eps * torch.exp(logs_q)
+    z_p = residual_coupling_block(_sub(sd, "flow."), z, causal=h["causal"])
+    return melvae_decode(sd, z, h), z_p, logs_q

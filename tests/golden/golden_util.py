@@ -62,3 +62,16 @@ def digest(arr):
     a = np.asarray(arr, dtype=np.float64).reshape(-1)
     idx = (np.arange(DIGEST_SAMPLES, dtype=np.int64) * 2654435761 + 12345) % a.size
     return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[idx]]).astype(np.float64)
+
+
+# mel-VAE hyper-parameters used by the fixtures (the reference's own JSON for backup/flows.py is absent)
+MELVAE_CONFIGS = {
+    "amp1_causal": dict(latent_dim=8, use_vae=True, downsample_channels=[12, 16, 24], downsample_rates=[2, 4],
+                        upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=32, resblock="1",
+                        resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]],
+                        activation="snakebeta", snake_logscale=True, causal=True, flow_hidden_channels=16),
+    "amp2_same": dict(latent_dim=8, use_vae=True, downsample_channels=[12, 16, 24], downsample_rates=[2, 4],
+                      upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=32, resblock="2",
+                      resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 3], [1, 3]],
+                      activation="snake", snake_logscale=True, causal=False, flow_hidden_channels=16),
+}

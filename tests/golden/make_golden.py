@@ -46,7 +46,33 @@ def install_stubs():
     mod("dac.nn.layers", Snake1d=_Missing, WNConv1d=WNConv1d, WNConvTranspose1d=WNConvTranspose1d)
     mod("dac.nn.quantize", ResidualVectorQuantize=_Missing)
     mod("vector_quantize_pytorch", ResidualVQ=_Missing, FSQ=_Missing)
-    mod("alias_free_torch", Activation1d=_Missing)
+    # alias-free-torch is absent: Activation1d below is OUR restatement (oracle/kalle_oracle.py activation1d, parity
+    # unpinned) wearing the package's module/attribute names, so that the reference's BigVGANFlowVAE can be run and the
+    # wiring around it pinned.
+    sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+    import kalle_oracle as ko
+
+    class _Resample(nn.Module):
+        def __init__(self, nested):
+            super().__init__()
+            filt = ko.kaiser_sinc_filter1d(0.25, 0.3, 12).view(1, 1, -1)
+            if nested:
+                self.lowpass = _Resample(False)
+            else:
+                self.register_buffer("filter", filt)
+
+    class Activation1d(nn.Module):
+        def __init__(self, activation, up_ratio=2, down_ratio=2, up_kernel_size=12, down_kernel_size=12):
+            super().__init__()
+            self.act = activation
+            self.upsample = _Resample(False)
+            self.downsample = _Resample(True)
+
+        def forward(self, x):
+            f = self.upsample.filter.view(-1)
+            return ko.downsample1d_2x(self.act(ko.upsample1d_2x(x, f)), f)
+
+    mod("alias_free_torch", Activation1d=Activation1d)
     ta = mod("torchaudio")
     ta.transforms = mod("torchaudio.transforms")
     mod("k_diffusion")
@@ -263,6 +289,35 @@ def main():
             z = pt.encode(wav)              # mean || scale (bottleneck is a pass-through in this reference)
             rec = pt.decode(z[:, :4])
         save(f"oobleck_vae_{tag}", z=z, rec=rec)
+    # ---- mel-VAE (backup/flows.py) ---------------------------------------------------------------------------------------
+    sys.path.insert(0, os.path.join(REF, "backup"))
+    import flows as rf
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+
+    melvae_inv = {}
+    for tag, h in gu.MELVAE_CONFIGS.items():
+        h = AttrDict(h)
+        vae = load_seeded(rf.BigVGANFlowVAE(h), 30)
+        melvae_inv[tag] = {k: list(v.shape) for k, v in vae.state_dict().items()}
+        wav = T(gu.make_input("melwav", (B, 1, 256), 30, 0.5))
+        eps = T(gu.make_input("meleps", (B, h.latent_dim, 256 // int(np.prod(h.downsample_rates))), 30))
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **k: eps
+        try:
+            with torch.no_grad():
+                enc = vae.extract_latents(wav)
+                rec, (z_p, logs_q, _, _) = vae(wav)
+                rec_sampled = vae.inference_from_latents(enc, do_sample=True)
+                rec_mean = vae.inference_from_latents(enc[:, :h.latent_dim], do_sample=False)
+                rs_in = T(gu.make_input("rs", (B, 16, 64), 31))
+                rs_out = vae.audio_encoder.generator[3](rs_in)
+        finally:
+            torch.randn_like = orig
+        assert torch.equal(rec, rec_sampled)
+        save(f"melvae_{tag}", enc=enc, rec=rec, z_p=z_p, logs_q=logs_q, rec_mean=rec_mean, rs_out=rs_out)
+
     # ---- state-dict key/shape inventories (the drop-in contract) ---------------------------------
     import json
     inv = {}
@@ -274,6 +329,8 @@ def main():
     cfg["model"]["encoder"]["config"]["use_snake"] = True
     cfg["model"]["decoder"]["config"]["use_snake"] = True
     inv["oobleck_autoencoder"] = {k: list(v.shape) for k, v in create_model_from_config(cfg).state_dict().items()}
+    for tag, v in melvae_inv.items():
+        inv[f"melvae_{tag}"] = v
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(inv, f, indent=0, sort_keys=True)
     print("done")

@@ -131,3 +131,18 @@ def test_inverse_lr_schedule():
         lrs.append(opt.param_groups[0]["lr"])
     exp = [(1 - 0.9 ** (e + 1)) * (1 + e / 10.0) ** -0.5 for e in (1, 2, 3)]
     assert all(abs(a - b) < 1e-6 for a, b in zip(lrs, exp))
+
+
+@pytest.mark.parametrize("tag", ["amp1_causal", "amp2_same"])
+def test_melvae_state_dict_matches_reference(tag):
+    """backup/flows.py BigVGANFlowVAE: same keys / shapes as the reference module built from the same hyper-parameters"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import golden_util as gu
+    from kalle_audio_amd.flows import BigVGANFlowVAE
+    m = BigVGANFlowVAE(gu.MELVAE_CONFIGS[tag])
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == _inventory()[f"melvae_{tag}"]
+    with pytest.raises(RuntimeError):
+        m.extract_latents(torch.zeros(1, 1, 64))      # CPU tensors are refused, not emulated
+    m.remove_weight_norm()
+    assert "conv_pre.weight" in m.state_dict() and "conv_pre.weight_g" not in m.state_dict()

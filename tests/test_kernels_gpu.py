@@ -1,10 +1,15 @@
 """-m gpu: every HIP kernel called through the C-ABI, checked against plain torch fp32 math of the same op
 (torch is only the checker here; the product path never calls these torch ops)."""
 import math
+import os
+import sys
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import kalle_oracle as ko  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -407,3 +412,55 @@ def test_snake(ops, dev):
     b = 0.3 * _mk((8,), dev, seed=72)
     ref = x + torch.sin(x * a.exp()[None, :, None]) ** 2 / (b.exp()[None, :, None] + 1e-9)
     assert rel_l2(conv_ops.snake_beta(x, a, b), ref) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1, 7, 255, 256, 257, 1000])
+@pytest.mark.parametrize("beta", [False, True])
+def test_act1d_matches_oracle(ops, dev, L, beta):
+    """fused 2x-up FIR -> snake -> 2x-down FIR kernel vs the restated alias-free-torch Activation1d (edges included)"""
+    from kalle_audio_amd import conv_ops
+    torch.manual_seed(L)
+    x = torch.randn(2, 5, L)
+    a, b = 0.3 * torch.randn(5), 0.3 * torch.randn(5)
+    want = ko.activation1d(x, a, b if beta else None, logscale=True)
+    filt = conv_ops.kaiser_sinc_filter12(dev)
+    assert torch.equal(filt.cpu(), ko.kaiser_sinc_filter1d(0.25, 0.3, 12))
+    got = conv_ops.act1d(x.to(dev), filt, a.to(dev), (b if beta else a).to(dev), True)
+    assert (got.cpu() - want).abs().max() < 2e-5
+    gb = conv_ops.act1d(x.to(dev).bfloat16(), filt, a.to(dev), (b if beta else a).to(dev), True)
+    assert (gb.float().cpu() - want).abs().max() < 0.06
+
+
+@pytest.mark.gpu
+def test_conv1d_causal_leaky_gate_scale_accumulate(ops, dev):
+    """the conv options the mel-VAE adds: left-only padding, LeakyReLU / WaveNet-gate input activation, output scale,
+    accumulate into y, trimmed transposed conv"""
+    from kalle_audio_amd import conv_ops
+    torch.manual_seed(5)
+    Bn, Cin, Cout, K, d, L = 2, 24, 40, 5, 3, 301
+    x = torch.randn(Bn, Cin, L)
+    w = torch.randn(Cout, Cin, K) / (Cin * K) ** 0.5
+    bias = torch.randn(Cout)
+    res = torch.randn(Bn, Cout, L)
+    y0 = torch.randn(Bn, Cout, L)
+    wp = conv_ops.weight_norm_fold(w.to(dev), None)
+    ref = F.conv1d(F.pad(F.leaky_relu(x, 0.2), (d * (K - 1), 0)), w, bias, dilation=d)
+    got = conv_ops.conv1d(x.to(dev), wp, bias.to(dev), Cout=Cout, K=K, padding=d * (K - 1), pad_right=0, dilation=d,
+                          act=3, act_param=0.2)
+    assert (got.cpu() - ref).abs().max() < 1e-4
+    acc = y0.to(dev).clone()
+    got = conv_ops.conv1d(x.to(dev), wp, bias.to(dev), Cout=Cout, K=K, padding=d * (K - 1), pad_right=0, dilation=d,
+                          act=3, act_param=0.2, residual=res.to(dev), out_scale=0.5, accumulate_into=acc)
+    assert got.data_ptr() == acc.data_ptr()
+    assert (got.cpu() - (y0 + 0.5 * (ref + res))).abs().max() < 1e-4
+    xg = torch.randn(Bn, 2 * Cin, L)
+    refg = F.conv1d(torch.tanh(xg[:, :Cin]) * torch.sigmoid(xg[:, Cin:]), w, bias, padding=2)
+    gotg = conv_ops.conv1d(xg.to(dev), wp, bias.to(dev), Cout=Cout, K=K, padding=2, act=4)
+    assert (gotg.cpu() - refg).abs().max() < 1e-4
+    s = 4
+    wt = torch.randn(Cin, Cout, 2 * s) / (Cin * 2) ** 0.5
+    wtp = conv_ops.weight_norm_fold(wt.to(dev), None, transposed=True)
+    reft = F.conv_transpose1d(x, wt, bias, stride=s)[:, :, :-s]
+    gott = conv_ops.conv_transpose1d(x.to(dev), wtp, bias.to(dev), Cout=Cout, K=2 * s, stride=s, padding=0, trim=s)
+    assert gott.shape == reft.shape and (gott.cpu() - reft).abs().max() < 1e-4

@@ -291,3 +291,55 @@ def test_snake_rms_fourier_modules(dev):
     ff = load_seeded(FourierFeatures(1, 256), 4, dev)
     t = T(np.linspace(0.05, 0.95, 6).astype(np.float32), dev)
     assert rel(ff(t[:, None]), fx("fourier_features")["y"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["amp1_causal", "amp2_same"])
+def test_melvae(dev, tag):
+    """backup/flows.py BigVGANFlowVAE drop-in against the reference-generated fixture (fp32 conv kernels: 1e-4)"""
+    from kalle_audio_amd.flows import BigVGANFlowVAE
+    f = fx(f"melvae_{tag}")
+    h = gu.MELVAE_CONFIGS[tag]
+    vae = load_seeded(BigVGANFlowVAE(h), 30, dev)
+    wav = T(gu.make_input("melwav", (B, 1, 256), 30, 0.5), dev)
+    eps = T(gu.make_input("meleps", (B, h["latent_dim"], 32), 30), dev)
+    with torch.no_grad():
+        enc = vae.extract_latents(wav)
+        assert rel(enc, f["enc"]) < 1e-4, rel(enc, f["enc"])
+        rec, (z_p, logs_q, _, _) = vae(wav, noise=eps)
+        assert rel(logs_q, f["logs_q"]) < 1e-4
+        assert rel(z_p, f["z_p"]) < 1e-4, rel(z_p, f["z_p"])
+        assert rel(rec, f["rec"]) < 2e-4, rel(rec, f["rec"])
+        rec2 = vae.inference_from_latents(enc, do_sample=True, noise=eps)
+        assert torch.equal(rec, rec2)
+        rec_mean = vae.inference_from_latents(enc[:, :h["latent_dim"]].contiguous(), do_sample=False)
+        assert rel(rec_mean, f["rec_mean"]) < 2e-4, rel(rec_mean, f["rec_mean"])
+        rs = vae.audio_encoder.generator[3](T(gu.make_input("rs", (B, 16, 64), 31), dev))
+        assert rel(rs, f["rs_out"]) < 1e-4
+        # flow is invertible: reverse(forward(z)) == z
+        z = torch.randn(B, h["latent_dim"], 40, device=dev)
+        back = vae.flow(vae.flow(z, None), None, reverse=True)
+        assert rel(back, z) < 1e-5
+        # weight-norm removal leaves the function unchanged
+        vae.remove_weight_norm()
+        assert rel(vae.inference_from_latents(enc, do_sample=True, noise=eps), f["rec"]) < 2e-4
+
+
+@pytest.mark.gpu
+def test_melvae_ragged_lengths_against_oracle(dev):
+    """lengths that are not multiples of any tile (and > one 256-sample act1d segment), other seed, bf16 I/O smoke"""
+    from kalle_audio_amd.flows import BigVGANFlowVAE
+    h = gu.MELVAE_CONFIGS["amp1_causal"]
+    vae = load_seeded(BigVGANFlowVAE(h), 77, dev)
+    sd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    z = torch.from_numpy(gu.make_input("zz", (1, h["latent_dim"], 173), 77))
+    want = ko.melvae_decode(sd, z, h)
+    with torch.no_grad():
+        got = vae.inference_from_latents(z.to(dev), do_sample=False)
+    assert got.shape == want.shape == (1, 1, 173 * 8)
+    assert rel(got, want) < 2e-4, rel(got, want)
+    wav = torch.from_numpy(gu.make_input("ww", (3, 1, 1003), 77, 0.5))
+    want = ko.melvae_encoder(ko._sub(sd, "audio_encoder."), wav, h["downsample_rates"])
+    with torch.no_grad():
+        got = vae.extract_latents(wav.to(dev))
+    assert rel(got, want) < 1e-4, rel(got, want)

@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/kalle_oracle.py, own fp32 restatement) against the golden vectors that
 tests/golden/make_golden.py produced by running the reference itself.  Tolerance: fp32, rtol 1e-5-ish
 (relative L2 <= 2e-6 on tensors, 1e-4 relative on gradient digests which include long sums)."""
+import math
 import os
 import sys
 
@@ -188,3 +189,46 @@ def test_oobleck(snake):
     z = ko.pretransform_encode(sd, wav, [2, 4, 5], snake, scale=0.8)
     rec = ko.pretransform_decode(sd, z[:, :4], [2, 4, 5], snake, scale=0.8, final_tanh=snake)
     close(z, f["z"], 1e-5); close(rec, f["rec"], 1e-5)
+
+
+def melvae_state(tag):
+    import json
+    inv = json.load(open(os.path.join(G, "state_dict_keys.json")))[f"melvae_{tag}"]
+    shapes = [(k, tuple(v)) for k, v in inv.items() if not k.endswith(".filter")]
+    return {k: T(v) for k, v in gu.make_state(shapes, 30).items()}
+
+
+@pytest.mark.parametrize("tag", ["amp1_causal", "amp2_same"])
+def test_melvae(tag):
+    """backup/flows.py BigVGANFlowVAE: encoder / ResStack / flow / decoder wiring against the reference run
+    (Activation1d itself is a restatement on both sides: parity unpinned for its taps, see the oracle header)."""
+    f = fx(f"melvae_{tag}")
+    h = gu.MELVAE_CONFIGS[tag]
+    sd = melvae_state(tag)
+    wav = T(gu.make_input("melwav", (B, 1, 256), 30, 0.5))
+    eps = T(gu.make_input("meleps", (B, h["latent_dim"], 32), 30))
+    with torch.no_grad():
+        enc = ko.melvae_encoder(ko._sub(sd, "audio_encoder."), wav, h["downsample_rates"])
+        close(enc, f["enc"])
+        rec, z_p, logs_q = ko.melvae_forward(sd, wav, eps, h)
+        close(rec, f["rec"], 1e-5)
+        close(z_p, f["z_p"], 1e-5)
+        close(logs_q, f["logs_q"])
+        close(ko.melvae_decode(sd, enc[:, :h["latent_dim"]], h), f["rec_mean"], 1e-5)
+        rs = ko.res_stack(ko._sub(sd, "audio_encoder.generator.3."), T(gu.make_input("rs", (B, 16, 64), 31)))
+        close(rs, f["rs_out"])
+
+
+def test_activation1d_properties():
+    """the anti-aliased activation has no reference fixture (alias-free-torch is absent): check the properties the
+    published design guarantees - unit DC gain of the 12-tap filter, symmetric taps, and that up->down without the
+    non-linearity reproduces a band-limited signal."""
+    filt = ko.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    assert abs(filt.sum().item() - 1.0) < 1e-6
+    assert torch.allclose(filt, filt.flip(0), atol=1e-7)
+    t = torch.arange(400, dtype=torch.float32)
+    x = torch.sin(2 * math.pi * 0.02 * t).view(1, 1, -1)
+    y = ko.downsample1d_2x(ko.upsample1d_2x(x, filt), filt)
+    assert (y - x)[..., 20:-20].abs().max() < 2e-3
+    const = torch.full((1, 2, 50), 0.7)
+    assert torch.allclose(ko.upsample1d_2x(const, filt), torch.full((1, 2, 100), 0.7), atol=1e-6)
