@@ -212,32 +212,49 @@ int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * 1-D convolution stack of the audio VAEs (no MFMA; LDS line buffers, coalesced HBM).
  * Layout (B, C, L) fp32 or bf16 activations, fp32 weights (weight-norm already folded: w = g * v/||v||).
  */
-/* fold weight norm and repack to the kernels' weight layout [Cin][K][Cout] fp32 (once per forward; weights are frozen
- * in every reference script, factory.py:77-80):
+/* fold weight norm and repack to the kernels' weight layout [Cin][K][CoutP] fp32, CoutP = Cout rounded up to a multiple
+ * of 8 with the pad columns zeroed (w_packed must hold Cin*K*CoutP floats), so a wave's 8 output-channel weights of a
+ * tap are one aligned scalar load (once per forward; weights are frozen in every reference script, factory.py:77-80):
  *   transposed=0 (Conv1d):          v [Cout=d0][Cin=d1][K], g [Cout] -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co,:,:]||
  *   transposed=1 (ConvTranspose1d): v [Cin=d0][Cout=d1][K], g [Cin]  -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci,:,:]||
  *   g == NULL: repack only (plain nn.Conv1d).   (dac.nn.layers.WNConv1d -> torch weight_norm; autoencoders.py:9) */
 int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                            int transposed, void* stream);
-/* y = conv1d(act(x), w, b, stride, padding, dilation) (+ residual) (-> tanh)
+/* activation descriptor of the conv kernels.  code: 0 none, 1 Snake / SnakeBeta x + sin^2(a x)/(b + 1e-9) with per-channel
+ * alpha / beta (exp() applied first when logscale; plain Snake passes alpha as beta too; blocks.py:301-339,
+ * backup/flows.py:51-62,113-126), 2 ELU, 3 LeakyReLU(negative_slope = param) (backup/flows.py:177-181,217,230),
+ * 4 (input side only) WaveNet gate tanh(x[:, :Cin]) * sigmoid(x[:, Cin:]) - x then has 2*Cin channels
+ * (backup/flows.py:614-620). */
+typedef struct kalle_act {
+    int32_t code;
+    int32_t logscale;
+    const float* alpha;
+    const float* beta;
+    float param;
+} kalle_act;
+/* what the conv kernels fuse into their store:
+ *   v = (conv + bias + residual) * out_scale;  if accumulate: v += y (previous contents: sum over the parallel AMP blocks,
+ *   backup/flows.py:517-523);  v = post_act(v) (the NEXT layer's input activation, per output channel, applied once here
+ *   instead of once per consumer tile);  if tanh: v = tanh(v) (autoencoders.py:185).  residual has y's shape and x's dtype. */
+typedef struct kalle_conv_epilogue {
+    const void* residual;
+    float out_scale;
+    int32_t accumulate;
+    int32_t tanh;
+    kalle_act post_act;
+} kalle_conv_epilogue;
+/* y = epilogue(conv1d(in_act(x), w, b, stride, padding, dilation)); in_act / epi may be NULL (= none / plain store).
  *   `padding` is the LEFT zero pad; the right pad is implied by Lout (symmetric padding: autoencoders.py:45,76;
- *   causal left-only padding: backup/flows.py:574-575,602-603).
- *   act: 0 none, 1 SnakeBeta (act_alpha/act_beta per input channel, exp() applied when act_logscale; Snake = pass
- *   alpha as beta too), 2 ELU, 3 LeakyReLU(negative_slope = act_param) (backup/flows.py:177-181,217,230),
- *   4 WaveNet gate tanh(x[:, :Cin]) * sigmoid(x[:, Cin:]) - x then has 2*Cin channels (backup/flows.py:614-620)
- *   (autoencoders.py:39-62 ResidualUnit, 64-81 EncoderBlock, 116-191 encoder/decoder stems; blocks.py:301-339)
- *   y = (conv + bias + residual) * out_scale, then post bits: 1 tanh (autoencoders.py:185), 2 add the previous contents
- *   of y first (sum over the parallel AMP blocks, backup/flows.py:517-523).  ksize <= 16. */
-int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, const void* residual,
-                     void* y, int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
-                     int padding, int dilation, int act, const float* act_alpha, const float* act_beta,
-                     int act_logscale, float act_param, float out_scale, int post, void* stream);
-/* y = conv_transpose1d(act(x), w, b, stride, padding), ksize <= 2*stride+1   (autoencoders.py:98-100 DecoderBlock);
+ *   causal left-only padding: backup/flows.py:574-575,602-603).  ksize <= 16.
+ *   (autoencoders.py:39-62 ResidualUnit, 64-81 EncoderBlock, 116-191 encoder/decoder stems) */
+int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y, int y_dtype, int B,
+                     int Cin, int Lin, int Cout, int Lout, int ksize, int stride, int padding, int dilation,
+                     const kalle_act* in_act, const kalle_conv_epilogue* epi, void* stream);
+/* y = epilogue(conv_transpose1d(in_act(x), w, b, stride, padding))   (autoencoders.py:98-100 DecoderBlock);
  * Lout may be shorter than the full length: the causal variant trims the last `stride` outputs (backup/flows.py:383-384) */
 int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
-                               int padding, int act, const float* act_alpha, const float* act_beta,
-                               int act_logscale, float act_param, void* stream);
+                               int padding, const kalle_act* in_act, const kalle_conv_epilogue* epi, void* stream);
 /* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
  * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)
  * -> 2x FIR low-pass downsample.  x, y: (B, C, L) fp32 or bf16; filter12: the 12 fp32 taps. */

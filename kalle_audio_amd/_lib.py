@@ -43,6 +43,18 @@ class GemmEpilogue(ctypes.Structure):
     ]
 
 
+class Act(ctypes.Structure):
+    """Mirror of `kalle_act`."""
+    _fields_ = [("code", ctypes.c_int32), ("logscale", ctypes.c_int32), ("alpha", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p), ("param", ctypes.c_float)]
+
+
+class ConvEpilogue(ctypes.Structure):
+    """Mirror of `kalle_conv_epilogue`."""
+    _fields_ = [("residual", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
+                ("tanh", ctypes.c_int32), ("post_act", Act)]
+
+
 _CTYPE = {
     "int": ctypes.c_int,
     "int32_t": ctypes.c_int32,

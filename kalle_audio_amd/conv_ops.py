@@ -10,22 +10,33 @@ from .ops import _dt, _p, _stream
 
 def weight_norm_fold(v, g, transposed=False):
     """v: Conv1d [Cout,Cin,K] (or ConvTranspose1d [Cin,Cout,K] when transposed), g: [dim0] or None.
-    Returns the packed fp32 weight [Cin][K][Cout]."""
+    Returns the packed fp32 weight [Cin][K][roundup(Cout, 8)] (pad columns zero)."""
     lib = _lib.load()
     v = v.detach().float().contiguous()
     d0, d1, K = v.shape
     cin, cout = (d0, d1) if transposed else (d1, d0)
     gg = g.detach().float().contiguous().view(-1) if g is not None else None
-    w = torch.empty((cin, K, cout), device=v.device, dtype=torch.float32)
+    w = torch.empty((cin, K, (cout + 7) // 8 * 8), device=v.device, dtype=torch.float32)   # Cout padded to 8
     check(lib.kalle_weight_norm_fold(_p(v), _p(gg), _p(w), d0, d1, K, int(transposed), _stream()),
           "kalle_weight_norm_fold")
     return w
 
 
+def _act_struct(code, alpha, beta, logscale, param):
+    return _lib.Act(int(code), int(bool(logscale)), _p(alpha), _p(beta), float(param))
+
+
+def _epilogue(residual, out_scale, accumulate, tanh, post_act):
+    """post_act: None or (code, alpha, beta, logscale, param) - the next layer's input activation, applied at the store"""
+    pa = _act_struct(*post_act) if post_act is not None else _lib.Act(0, 0, None, None, 0.0)
+    return _lib.ConvEpilogue(_p(residual), float(out_scale), int(accumulate), int(tanh), pa)
+
+
 def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0, alpha=None, beta=None,
            logscale=True, residual=None, post=0, out_dtype=None, pad_right=None, act_param=0.0, out_scale=1.0,
-           accumulate_into=None):
-    """padding = left pad; pad_right defaults to the same (symmetric). act: 0 none, 1 snake(-beta), 2 ELU, 3 LeakyReLU"""
+           accumulate_into=None, post_act=None):
+    """padding = left pad; pad_right defaults to the same (symmetric). act: 0 none, 1 snake(-beta), 2 ELU, 3 LeakyReLU,
+    4 WaveNet gate.  Store: (conv + bias + residual) * out_scale (+= accumulate_into) -> post_act -> tanh (post=1)."""
     lib = _lib.load()
     x = x.contiguous()
     B, Cin, Lin = x.shape
@@ -36,29 +47,32 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
     if accumulate_into is not None:
         y = accumulate_into
         assert y.is_contiguous() and tuple(y.shape) == (B, Cout, Lout)
-        post |= 2
     else:
         y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
     if residual is not None:
         residual = residual.contiguous()
         assert residual.dtype == x.dtype and residual.shape == y.shape
-    check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(residual), _p(y), _dt(y), B, Cin, Lin, Cout,
-                               Lout, K, stride, padding, dilation, act, _p(alpha), _p(beta), int(logscale), act_param, out_scale, post,
-                               _stream()), "kalle_conv1d_fwd")
+    ia = _act_struct(act, alpha, beta, logscale, act_param)
+    ep = _epilogue(residual, out_scale, accumulate_into is not None, post & 1, post_act)
+    check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout, Lout, K, stride,
+                               padding, dilation, ctypes.addressof(ia), ctypes.addressof(ep), _stream()),
+          "kalle_conv1d_fwd")
     return y
 
 
 def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alpha=None, beta=None, logscale=True,
-                     out_dtype=None, trim=0, act_param=0.0):
+                     out_dtype=None, trim=0, act_param=0.0, post_act=None):
     """trim: drop the last `trim` outputs (causal transposed conv)"""
     lib = _lib.load()
     x = x.contiguous()
     B, Cin, Lin = x.shape
     Lout = (Lin - 1) * stride - 2 * padding + K - trim
     y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
+    ia = _act_struct(act, alpha, beta, logscale, act_param)
+    ep = _epilogue(None, 1.0, False, False, post_act)
     check(lib.kalle_conv_transpose1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout,
-                                         Lout, K, stride, padding, act, _p(alpha), _p(beta), int(logscale),
-                                         act_param, _stream()), "kalle_conv_transpose1d_fwd")
+                                         Lout, K, stride, padding, ctypes.addressof(ia), ctypes.addressof(ep),
+                                         _stream()), "kalle_conv_transpose1d_fwd")
     return y
 
 

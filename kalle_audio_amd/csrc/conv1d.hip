@@ -1,14 +1,24 @@
-// 1-D convolution stack of the audio VAEs (gfx950, vector ALUs only - no MFMA, per the north-star spec):
-// weight-norm fold, SnakeBeta/ELU fused into the input staging, dilated / strided conv and transposed conv with
-// LDS line buffers, residual add + tanh fused into the store.
+// 1-D convolution stacks of the audio VAEs (gfx950, vector ALUs only - no MFMA, per the north-star spec):
+// weight-norm fold, input activation (SnakeBeta / ELU / LeakyReLU / WaveNet gate) fused into the input staging,
+// dilated / strided / causal conv and transposed conv, and (conv + bias + residual) * scale (+= y) -> activation -> tanh
+// fused into the store.
 // Reference: stable_audio_tools/models/autoencoders.py:39-62 (ResidualUnit), 64-81 (EncoderBlock), 83-114
 // (DecoderBlock), 116-191 (Oobleck encoder/decoder); blocks.py:301-339 (SnakeBeta); dac.nn.layers.WNConv1d ->
-// torch.nn.utils.weight_norm (w = g * v / ||v||, norm over all dims but 0).
+// torch.nn.utils.weight_norm (w = g * v / ||v||, norm over all dims but 0); backup/flows.py (mel-VAE).
 //
 // Layout: activations (B, C, L) row-major (L contiguous, as torch), fp32 or bf16; weights are repacked once per
-// forward by kalle_weight_norm_fold into [Cin][K][Cout] fp32 so that a workgroup's weight slab is contiguous in Cout.
-// Tile: 64 output channels x 64 output positions per 256-thread workgroup, 4x4 outputs per thread; input channels
-// are streamed 8 at a time through an LDS line buffer that holds the activated input span (with halo) once.
+// forward by kalle_weight_norm_fold into [Cin][K][CoutP] fp32 (CoutP = Cout rounded up to 8).
+//
+// Main kernels ("v2", stride-1 conv and every transposed conv): a wave owns 8 output channels for 64*LPT positions;
+// lane l handles positions l, l+64, ... so every LDS read of the input span is lane-consecutive (conflict-free for any
+// dilation / alignment); the 8 weights of a (ci, tap) are wave-uniform, so they are fetched with SCALAR loads straight
+// from the packed array (scalar cache / L2) and feed v_pk_fma_f32 as SGPR operands - no LDS traffic for weights.  The
+// input span is staged through registers (global loads of chunk n+1 in flight while chunk n is computed), activated when
+// it is written to LDS, double-buffered, one barrier per 8-channel chunk; the (channel, tap) loop is software-pipelined by
+// hand (loads of step t+1 issued right after the wait for step t).  A transposed conv of stride S is S independent
+// ceil(K/S)-tap convolutions (one per output phase) run back to back by the same workgroup.
+// Fallback kernels ("v1": strided conv, gated input, mixed dtypes): 64 co x 64 positions per workgroup, 4x4 per thread.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/kalle_hip.h"
 
@@ -18,13 +28,18 @@ constexpr int CO_T = 64, L_T = 64, CI_T = 8;
 constexpr int MAX_SPAN = 576;   // (L_T-1)*stride + (K-1)*dil + 1 must fit
 constexpr int MAX_K = 16;
 
+__device__ __forceinline__ float fast_sin(float x) {   // v_sin_f32 takes revolutions; fract() does the range reduction
+    const float r = x * 0.15915494309189535f;
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
+}
+// act: 1 snake(-beta) x + sin^2(a x) * inv_b, 2 ELU, 3 LeakyReLU(a)
 __device__ __forceinline__ float act_apply(float x, int act, float a, float inv_b) {
-    if (act == 1) {  // SnakeBeta: x + sin^2(x*alpha)/(beta+1e-9)
-        const float s = sinf(x * a);
+    if (act == 1) {
+        const float s = fast_sin(x * a);
         return x + inv_b * s * s;
     }
-    if (act == 2) return x > 0.f ? x : (__expf(x) - 1.f);  // ELU(alpha=1)
-    if (act == 3) return x > 0.f ? x : x * a;              // LeakyReLU(negative_slope = a)
+    if (act == 2) return x > 0.f ? x : (__expf(x) - 1.f);
+    if (act == 3) return x > 0.f ? x : x * a;
     return x;
 }
 
@@ -41,12 +56,38 @@ __device__ __forceinline__ void st1(void* p, int64_t i, float v) {
 
 struct ConvParams {
     const void* x; const float* w; const float* bias; const void* res; void* y;
-    int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, act, post;
+    int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, act, post;   // post bits: 1 tanh, 2 accumulate into y
     const float* aa; const float* ab; int logscale;
     float act_param;
     float out_scale;
-    int xC;   // channels of the x tensor (2*Cin for the gated activation, else Cin)
+    int CoutP;  // row stride of the packed weights = Cout rounded up to 8 (pad columns are zero)
+    int xC;     // channels of the x tensor (2*Cin for the gated activation, else Cin)
+    int pact; const float* paa; const float* pab; int plogscale; float pparam;   // activation applied to the output
+    int nco, ntile, co_fast;   // v2 grid: blockIdx.x enumerates (position tile, channel tile), channel tile fastest if co_fast
 };
+
+// (conv + bias + residual) * out_scale (+= y) -> post activation -> tanh -> store
+template <bool XF32, bool YF32, bool RES = true>
+__device__ __forceinline__ void conv_store(const ConvParams& p, int co, int64_t oi, float v, float bv, float pa,
+                                           float pinv_b) {
+    v += bv;
+    if (RES && p.res) v += ld1<XF32>(p.res, oi);
+    v *= p.out_scale;
+    if (p.post & 2) v += ld1<YF32>(p.y, oi);
+    if (p.pact) v = act_apply(v, p.pact, pa, pinv_b);
+    if (p.post & 1) v = tanhf(v);
+    st1<YF32>(p.y, oi, v);
+}
+__device__ __forceinline__ void post_act_params(const ConvParams& p, int co, float& pa, float& pinv_b) {
+    pa = p.pparam;
+    pinv_b = 0.f;
+    if (p.pact == 1) {
+        pa = p.paa[co];
+        float bb = p.pab[co];
+        if (p.plogscale) { pa = __expf(pa); bb = __expf(bb); }
+        pinv_b = 1.f / (bb + 1e-9f);
+    }
+}
 
 template <bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void conv1d_kernel(ConvParams p) {
@@ -94,7 +135,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvParams p) {
             const int c = ck / p.K, k = ck - c * p.K;
             const int ci = ci0 + c;
             float v = 0.f;
-            if (ci < p.Cin && co0 + co < p.Cout) v = p.w[((int64_t)ci * p.K + k) * p.Cout + co0 + co];
+            if (ci < p.Cin && co0 + co < p.Cout) v = p.w[((int64_t)ci * p.K + k) * p.CoutP + co0 + co];
             Ws[c][k][co] = v;
         }
         __syncthreads();
@@ -118,17 +159,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvParams p) {
         const int co = co0 + 4 * tc + i;
         if (co >= p.Cout) continue;
         const float bv = p.bias ? p.bias[co] : 0.f;
+        float pa, pinv_b;
+        post_act_params(p, co, pa, pinv_b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int l = l0 + 4 * tl + j;
             if (l >= p.Lout) continue;
-            const int64_t oi = ((int64_t)b * p.Cout + co) * p.Lout + l;
-            float v = acc[i][j] + bv;
-            if (p.res) v += ld1<XF32>(p.res, oi);
-            v *= p.out_scale;
-            if (p.post & 2) v += ld1<YF32>(p.y, oi);   // accumulate into y (sum over parallel AMP blocks)
-            if (p.post & 1) v = tanhf(v);
-            st1<YF32>(p.y, oi, v);
+            conv_store<XF32, YF32>(p, co, ((int64_t)b * p.Cout + co) * p.Lout + l, acc[i][j], bv, pa, pinv_b);
         }
     }
 }
@@ -177,7 +214,7 @@ __global__ __launch_bounds__(256) void convT1d_kernel(ConvParams p) {
             const int c = ck / p.K, k = ck - c * p.K;
             const int ci = ci0 + c;
             float v = 0.f;
-            if (ci < p.Cin && co0 + co < p.Cout) v = p.w[((int64_t)ci * p.K + k) * p.Cout + co0 + co];
+            if (ci < p.Cin && co0 + co < p.Cout) v = p.w[((int64_t)ci * p.K + k) * p.CoutP + co0 + co];
             Ws[c][k][co] = v;
         }
         __syncthreads();
@@ -205,16 +242,283 @@ __global__ __launch_bounds__(256) void convT1d_kernel(ConvParams p) {
         const int co = co0 + 4 * tc + i;
         if (co >= p.Cout) continue;
         const float bv = p.bias ? p.bias[co] : 0.f;
+        float pa, pinv_b;
+        post_act_params(p, co, pa, pinv_b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int l = l0 + 4 * tl + j;
             if (l >= p.Lout) continue;
-            st1<YF32>(p.y, ((int64_t)b * p.Cout + co) * p.Lout + l, acc[i][j] + bv);
+            conv_store<XF32, YF32>(p, co, ((int64_t)b * p.Cout + co) * p.Lout + l, acc[i][j], bv, pa, pinv_b);
         }
     }
 }
 
-// weight norm fold + repack to [Cin][K][Cout]. One workgroup per index of dim 0 of v (the weight_norm dim).
+
+
+// ------------------------------------------------------------------------------------------------ v2 core
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* cfloat_p;   // constant address space: uniform loads become SMEM
+
+struct ConvPass {        // one pass of the core = one output phase
+    int in0;             // x index of span slot 0
+    int span;            // slots to stage (<= SPAN)
+    int xs0;             // span slot read by tap 0 at local position 0
+    int ntaps;           // taps per input channel (K, or the taps of this phase of a transposed conv)
+    int xtap;            // span-slot advance per tap (dilation, or -1)
+    int64_t w0;          // first weight row of ci = 0, in rows of CoutP
+    int64_t wtap, wchan; // weight row advance per tap / from the last tap of ci to the first tap of ci + 1
+    int64_t o0;          // output position of local position 0
+    int ostride;         // output positions per local position (1, or the stride of a transposed conv)
+};
+
+// COW output channels per wave, 64*LPT positions per wave; WCO of the 4 waves are spread over output channels, the other
+// 4/WCO over positions (tiny-Cout layers: WCO = 1); CI input channels per staged chunk; SPAN = LDS row length.
+template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32>
+__device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g, float (*Xs)[SPAN], int b, int co_w,
+                                          int lane, int wave, int wave_l) {
+    constexpr int LW = 64 * LPT;
+    constexpr int NS = SPAN / 64;                     // span slots per lane
+    constexpr int NH = CI / 4;                        // channels of a chunk staged by one wave
+    const int nchunks = (p.Cin + CI - 1) / CI;
+
+    f32x2 acc[COW][LPT / 2];                          // packed along positions: (l_2j, l_2j+1) share one v_pk_fma_f32
+#pragma unroll
+    for (int i = 0; i < COW; ++i)
+#pragma unroll
+        for (int j = 0; j < LPT / 2; ++j) acc[i][j] = f32x2{0.f, 0.f};
+    // the residual is loaded straight into the accumulators up front (all loads in flight together, their latency hidden
+    // behind the first chunk) - in the store loop every load would sit behind the previous store (they may alias)
+    if (p.res) {                                      // clamped addresses, no branches: invalid lanes are never stored
+#pragma unroll
+        for (int i = 0; i < COW; ++i) {
+            const int64_t rb = ((int64_t)b * p.Cout + min(co_w + i, p.Cout - 1)) * p.Lout;
+#pragma unroll
+            for (int j = 0; j < LPT / 2; ++j) {
+                const int64_t la = g.o0 + (int64_t)(wave_l * LW + lane + 128 * j) * g.ostride;
+                const int64_t lb = la + 64 * g.ostride;
+                const float ra = ld1<XF32>(p.res, rb + min(max(la, (int64_t)0), (int64_t)p.Lout - 1));
+                const float rc = ld1<XF32>(p.res, rb + min(max(lb, (int64_t)0), (int64_t)p.Lout - 1));
+                acc[i][j] = f32x2{ra, rc};
+            }
+        }
+    }
+
+    float stg[NH][NS];                                // wave w stages channels w, w+4, ... of a chunk
+    float s_a[NH], s_b[NH];                           // their activation parameters (scalar loads, issued with the data)
+    const cfloat_p aa_c = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.aa));
+    const cfloat_p ab_c = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.ab));
+    auto gload = [&](int ci0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int ci = ci0 + wave + 4 * h;
+            if (p.act == 1) {
+                s_a[h] = aa_c[min(ci, p.Cin - 1)];
+                s_b[h] = ab_c[min(ci, p.Cin - 1)];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int sp = lane + 64 * s, li = g.in0 + sp;
+                float v = 0.f;
+                if (sp < g.span && ci < p.Cin && li >= 0 && li < p.Lin)
+                    v = ld1<XF32>(p.x, ((int64_t)b * p.xC + ci) * p.Lin + li);
+                stg[h][s] = v;
+            }
+        }
+    };
+    auto lstore = [&](int ci0, int buf) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int c = wave + 4 * h, ci = ci0 + c;
+            float a = p.act_param, inv_b = 0.f;
+            if (p.act == 1) {
+                a = s_a[h];
+                float bb = s_b[h];
+                if (p.logscale) { a = __expf(a); bb = __expf(bb); }
+                inv_b = 1.f / (bb + 1e-9f);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int sp = lane + 64 * s, li = g.in0 + sp;
+                if (sp < g.span) {
+                    float v = stg[h][s];
+                    if (p.act && ci < p.Cin && li >= 0 && li < p.Lin) v = act_apply(v, p.act, a, inv_b);
+                    Xs[buf * CI + c][sp] = v;
+                }
+            }
+        }
+    };
+    const cfloat_p wbase = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.w)) + co_w;
+    const cfloat_p wlast = wbase + ((int64_t)p.Cin * p.K - 1) * p.CoutP;
+    const int xwrap = SPAN - (g.ntaps - 1) * g.xtap;
+    const int64_t wtap = g.wtap * p.CoutP, wchan = g.wchan * p.CoutP;
+
+    // The scalar weight loads only run one step ahead, so they must hit in L2: every thread touches one 64-B line of the
+    // NEXT chunk's weight rows with a vector load (same vmcnt batch as the x loads), which pulls the rows of all four
+    // waves from HBM / MALL into this XCD's L2 a whole chunk before they are needed.
+    constexpr int LPR = WCO * COW * 4 / 64 > 0 ? WCO * COW * 4 / 64 : 1;   // 64-B lines per weight row of this workgroup
+    float wt0 = 0.f, wt1 = 0.f;                       // touched values: consumed (= waited for) only at the next lstore
+    auto wprefetch = [&](int ci0) {
+        const int per_c = g.ntaps * LPR;
+        const int total = min(CI, p.Cin - ci0) * per_c;
+        const int co_g = co_w - (wave % WCO) * COW;
+        auto touch = [&](int idx) {
+            idx = idx < total ? idx : 0;              // clamped, branch-free: a redundant touch of the first line
+            const int c = idx / per_c, rem = idx - c * per_c;
+            const int m = rem / LPR;
+            int col = co_g + 16 * (rem - m * LPR);
+            col = col < p.CoutP ? col : co_g;
+            const int64_t row = min(g.w0 + (int64_t)(ci0 + c) * p.K + (int64_t)m * g.wtap, (int64_t)p.Cin * p.K - 1);
+            return p.w[row * p.CoutP + col];
+        };
+        if (total > 0) {
+            wt0 = touch(threadIdx.x);
+            wt1 = touch(threadIdx.x + 256);
+        }
+    };
+    auto consume_touch = [&]() { asm volatile("" ::"v"(wt0), "v"(wt1)); };
+
+    wprefetch(0);
+    gload(0);
+    consume_touch();
+    if (nchunks > 1) wprefetch(CI);
+    lstore(0, 0);
+    __syncthreads();
+    for (int n = 0; n < nchunks; ++n) {
+        const int ci0 = n * CI, buf = n & 1;
+        if (n + 1 < nchunks) {
+            consume_touch();                             // (loads issued a whole chunk ago)
+            if (n + 2 < nchunks) wprefetch(ci0 + 2 * CI);
+            gload(ci0 + CI);
+        }
+        const int cmax = min(CI, p.Cin - ci0);
+        // flattened (channel, tap) loop, software-pipelined by hand: the loads of step t+1 are issued right after the
+        // wait for step t's operands, so LDS + scalar-cache latency hides behind the packed FMAs of step t.
+        // (scalar loads return out of order, so any wait on them is lgkmcnt(0): the wait must precede the prefetch.)
+        const int T = cmax * g.ntaps;
+        cfloat_p wr = wbase + (g.w0 + (int64_t)ci0 * p.K) * p.CoutP;
+        if (wr > wlast) wr = wlast;
+        const float* xs = &Xs[buf * CI][g.xs0 + wave_l * LW + lane];
+        int kk = 0;
+        f32x2 w0[COW / 2], w1[COW / 2];
+        f32x2 x0[LPT / 2], x1[LPT / 2];
+        auto ld = [&](f32x2 (&w)[COW / 2], f32x2 (&x)[LPT / 2]) {
+#pragma unroll
+            for (int i = 0; i < COW / 2; ++i) w[i] = f32x2{wr[2 * i], wr[2 * i + 1]};
+#pragma unroll
+            for (int j = 0; j < LPT / 2; ++j) x[j] = f32x2{xs[128 * j], xs[128 * j + 64]};
+            if (++kk == g.ntaps) { kk = 0; xs += xwrap; wr += wchan; } else { xs += g.xtap; wr += wtap; }
+            if (wr > wlast) wr = wlast;              // the one-step-ahead prefetch never leaves the array
+        };
+        // acc(l_2j, l_2j+1) += w_i * (x_2j, x_2j+1): the weight is one half of an SGPR pair, broadcast by op_sel (hipcc
+        // would copy odd weights into even SGPRs first, which makes it wait on the prefetch it has just issued)
+        auto fma = [&](const f32x2 (&w)[COW / 2], const f32x2 (&x)[LPT / 2]) {
+#pragma unroll
+            for (int j = 0; j < LPT / 2; ++j)
+#pragma unroll
+                for (int i = 0; i < COW / 2; ++i) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[2 * i][j]) : "s"(w[i]), "v"(x[j]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                        : "+v"(acc[2 * i + 1][j]) : "s"(w[i]), "v"(x[j]));
+                }
+        };
+        auto wait_lgkm = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (T > 0) {
+            ld(w0, x0);
+            int t = 0;
+            for (; t + 2 <= T; t += 2) {
+                wait_lgkm();
+                ld(w1, x1);
+                fma(w0, x0);
+                wait_lgkm();
+                ld(w0, x0);                          // step t+2 (may be one past the chunk: unused)
+                fma(w1, x1);
+            }
+            if (t < T) fma(w0, x0);
+        }
+        if (n + 1 < nchunks) lstore(ci0 + CI, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < COW; ++i) {
+        const int co = co_w + i;
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+        float pa, pinv_b;
+        post_act_params(p, co, pa, pinv_b);
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int64_t l = g.o0 + (int64_t)(wave_l * LW + lane + 64 * j) * g.ostride;
+            if (l < 0 || l >= p.Lout) continue;
+            conv_store<XF32, YF32, false>(p, co, ((int64_t)b * p.Cout + co) * p.Lout + l, acc[i][j >> 1][j & 1], bv, pa,
+                                          pinv_b);
+        }
+    }
+}
+
+template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void conv1d_v2_kernel(ConvParams p) {
+    constexpr int LT = 64 * LPT * (4 / WCO);
+    __shared__ float Xs[2 * CI + 1][SPAN];           // two buffers + one pad row for the one-step-ahead prefetch
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bt = p.co_fast ? blockIdx.x / p.nco : blockIdx.x % p.ntile;
+    const int bc = p.co_fast ? blockIdx.x % p.nco : blockIdx.x / p.ntile;
+    const int l0 = bt * LT;
+    ConvPass g;
+    g.in0 = l0 - p.pad;
+    g.span = (LT - 1) + (p.K - 1) * p.dil + 1;
+    g.xs0 = 0;
+    g.ntaps = p.K;
+    g.xtap = p.dil;
+    g.w0 = 0;
+    g.wtap = 1;
+    g.wchan = 1;
+    g.o0 = l0;
+    g.ostride = 1;
+    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane, wave,
+                                                    wave / WCO);
+}
+
+// transposed conv: output lo = q*S + r - pad (phase r < S, input position q):
+//   y[q*S + r - pad] = sum_ci sum_m x[q - m] w[ci, r + m*S, co],  m < ceil((K - r)/S)
+// i.e. S independent ceil(K/S)-tap convolutions whose outputs interleave.  One workgroup = one phase of one
+// (64*LPT*(4/WCO) input positions q) x (channel tile).  Workgroup ids are laid out so that the S phases of a tile differ
+// by multiples of 8: the hardware deals consecutive ids round-robin to the 8 XCDs, so all phases of a tile run on the
+// SAME XCD within a few ids of each other and their interleaved 4-byte stores merge in that XCD's L2 before write-back.
+template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void convT1d_v2_kernel(ConvParams p) {
+    constexpr int LT = 64 * LPT * (4 / WCO);
+    __shared__ float Xs[2 * CI + 1][SPAN];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = p.stride;
+    const int n = blockIdx.x;
+    const int r = (n >> 3) % S;
+    const int tile = (n / (8 * S)) * 8 + (n & 7);    // (position tile, channel tile) pair, position tiles fastest
+    if (tile >= p.ntile * p.nco) return;
+    const int bt = tile % p.ntile, bc = tile / p.ntile;
+    const int q0 = bt * LT;
+    const int mmax = (p.K + S - 1) / S;
+    ConvPass g;
+    g.ntaps = r < p.K ? (p.K - r + S - 1) / S : 0;
+    g.in0 = q0 - (mmax - 1);
+    g.span = LT + mmax - 1;
+    g.xs0 = mmax - 1;
+    g.xtap = -1;
+    g.w0 = r;
+    g.wtap = S;
+    g.wchan = p.K - (int64_t)(g.ntaps - 1) * S;
+    g.o0 = (int64_t)q0 * S + r - p.pad;
+    g.ostride = S;
+    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane, wave,
+                                                    wave / WCO);
+}
+
+// weight norm fold + repack to [Cin][K][CoutP] (CoutP = Cout rounded up to 8, pad columns zeroed). One workgroup per index of dim 0 of v (the weight_norm dim).
 //   conv:  v [Cout][Cin][K], g [Cout]  -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co]||
 //   convT: v [Cin][Cout][K], g [Cin]   -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci]||
 __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ v, const float* __restrict__ g,
@@ -222,6 +526,11 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
     __shared__ float red[16];
     const int o = blockIdx.x;
     const int per = d1 * K;
+    const int cout = transposed ? d1 : d0, coutp = (cout + 7) & ~7;
+    if (!transposed && o >= d0) {       // pad output channel: zero column
+        for (int i = threadIdx.x; i < per; i += 256) w[(int64_t)i * coutp + o] = 0.f;   // i = j*K + k
+        return;
+    }
     const float* vp = v + (int64_t)o * per;
     float scale = 1.f;
     if (g) {
@@ -233,11 +542,16 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < per; i += 256) {
         const int j = i / K, k = i - j * K;
         if (!transposed) {  // o = co, j = ci ; Cout = d0
-            w[((int64_t)j * K + k) * d0 + o] = vp[i] * scale;
+            w[((int64_t)j * K + k) * coutp + o] = vp[i] * scale;
         } else {            // o = ci, j = co ; Cout = d1
-            w[((int64_t)o * K + k) * d1 + j] = vp[i] * scale;
+            w[((int64_t)o * K + k) * coutp + j] = vp[i] * scale;
         }
     }
+    if (transposed)
+        for (int i = threadIdx.x; i < (coutp - d1) * K; i += 256) {
+            const int k = i / (coutp - d1), j = d1 + i - k * (coutp - d1);
+            w[((int64_t)o * K + k) * coutp + j] = 0.f;
+        }
 }
 
 template <bool F32>
@@ -249,7 +563,8 @@ __global__ __launch_bounds__(256) void snake_kernel(const void* __restrict__ x, 
         float a = alpha[c], b = beta[c];
         if (logscale) { a = __expf(a); b = __expf(b); }
         const float xv = ld1<F32>(x, i);
-        st1<F32>(y, i, act_apply(xv, 1, a, 1.f / (b + 1e-9f)));
+        const float sn = sinf(xv * a);            // accurate sine: this kernel is HBM-bound anyway
+        st1<F32>(y, i, xv + sn * sn / (b + 1e-9f));
     }
 }
 
@@ -323,28 +638,100 @@ extern "C" int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* f
 extern "C" int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                                       int transposed, void* stream) {
     if (!v || !w_packed || d0 <= 0 || d1 <= 0 || ksize <= 0) return KALLE_ERR_ARG;
-    KALLE_LAUNCH(wn_fold_kernel, dim3(d0), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
+    KALLE_LAUNCH(wn_fold_kernel, dim3(transposed ? d0 : ((d0 + 7) & ~7)), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
                        ksize, transposed);
     return kalle_check_launch();
 }
 
-extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias,
-                                const void* residual, void* y, int y_dtype, int B, int Cin, int Lin, int Cout, int Lout,
-                                int ksize, int stride, int padding, int dilation, int act, const float* act_alpha,
-                                const float* act_beta, int act_logscale, float act_param, float out_scale, int post,
+
+namespace {
+struct ActArgs { int code = 0; const float* alpha = nullptr; const float* beta = nullptr; int logscale = 0; float param = 0.f; };
+bool read_act(const kalle_act* a, ActArgs& o, bool input_side) {
+    if (!a) return true;
+    o.code = a->code; o.alpha = a->alpha; o.beta = a->beta; o.logscale = a->logscale; o.param = a->param;
+    if (o.code < 0 || o.code > (input_side ? 4 : 3)) return false;
+    if (o.code == 1 && (!o.alpha || !o.beta)) return false;
+    return true;
+}
+bool fill_params(ConvParams& p, const kalle_act* in_act, const kalle_conv_epilogue* epi) {
+    ActArgs ia, pa;
+    if (!read_act(in_act, ia, true)) return false;
+    p.act = ia.code; p.aa = ia.alpha; p.ab = ia.beta; p.logscale = ia.logscale; p.act_param = ia.param;
+    p.res = nullptr; p.out_scale = 1.f; p.post = 0;
+    if (epi) {
+        if (!read_act(&epi->post_act, pa, false)) return false;
+        p.res = epi->residual;
+        p.out_scale = epi->out_scale;
+        p.post = (epi->tanh ? 1 : 0) | (epi->accumulate ? 2 : 0);
+    }
+    p.pact = pa.code; p.paa = pa.alpha; p.pab = pa.beta; p.plogscale = pa.logscale; p.pparam = pa.param;
+    return true;
+}
+// positions-per-lane of the v2 tile: least padded work, slightly favouring the longer (better pipelined) tiles
+int pick_lpt(int64_t npos, int halo, int span) {
+    int best = 0;
+    double best_cost = 0;
+    const int lpts[3] = {8, 4, 2};
+    const double pen[3] = {1.0, 1.12, 1.4};
+    for (int i = 0; i < 3; ++i) {
+        const int lt = 64 * lpts[i];
+        if (lt + halo > span) continue;
+        const double cost = (double)((npos + lt - 1) / lt) * lt * pen[i];
+        if (!best || cost < best_cost) { best = lpts[i]; best_cost = cost; }
+    }
+    return best;
+}
+constexpr int V2_SPAN = 640;
+}  // namespace
+
+extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
+                                int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
+                                int padding, int dilation, const kalle_act* in_act, const kalle_conv_epilogue* epi,
                                 void* stream) {
     if (!x || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lout <= 0) return KALLE_ERR_ARG;
     if (ksize <= 0 || ksize > MAX_K || stride <= 0 || dilation <= 0 || padding < 0) return KALLE_ERR_ARG;
-    if ((L_T - 1) * stride + (ksize - 1) * dilation + 1 > MAX_SPAN) return KALLE_ERR_UNSUPPORTED;
     // `padding` is the LEFT pad; the right pad is implied by Lout (symmetric, 'same' or causal alike): taps beyond Lin read 0
     if ((int64_t)(Lout - 1) * stride - padding >= Lin) return KALLE_ERR_ARG;
-    if (act == 1 && (!act_alpha || !act_beta)) return KALLE_ERR_ARG;
-    if (B > 65535 || (Cout + CO_T - 1) / CO_T > 65535) return KALLE_ERR_ARG;
-    ConvParams p{x, w_packed, bias, residual, y, B, Cin, Lin, Cout, Lout, ksize, stride, padding, dilation, act, post,
-                 act_alpha, act_beta, act_logscale, act_param, out_scale, act == 4 ? 2 * Cin : Cin};
-    dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
+    if (B > 65535 || (Cout + 7) / 8 > 65535) return KALLE_ERR_ARG;
+    ConvParams p{};
+    if (!fill_params(p, in_act, epi)) return KALLE_ERR_ARG;
+    p.x = x; p.w = w_packed; p.bias = bias; p.y = y;
+    p.B = B; p.Cin = Cin; p.Lin = Lin; p.Cout = Cout; p.Lout = Lout; p.K = ksize; p.stride = stride; p.pad = padding;
+    p.dil = dilation; p.CoutP = (Cout + 7) & ~7; p.xC = p.act == 4 ? 2 * Cin : Cin;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
+    const int halo = (ksize - 1) * dilation;
+    // weights small enough to stay in one XCD's L2: run the channel tiles of a position tile back to back (x re-read hits L2)
+    p.co_fast = (int64_t)Cin * ksize * p.CoutP * 4 <= (2 << 20);
+    if (stride == 1 && p.act != 4 && xf == yf && !getenv("KALLE_CONV_V1")) {
+#define KALLE_CONV_V2(COW, LPT, WCO, CI, SPAN)                                                                         \
+    do {                                                                                                                \
+        p.ntile = (Lout + 64 * LPT * (4 / WCO) - 1) / (64 * LPT * (4 / WCO));                                          \
+        p.nco = (Cout + COW * WCO - 1) / (COW * WCO);                                                                   \
+        if ((int64_t)p.ntile * p.nco > 0x7fffffff) return KALLE_ERR_ARG;                                                \
+        dim3 g(p.ntile * p.nco, 1, B);                                                                                  \
+        if (xf) KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, true, true>), g, dim3(256), 0, st, p);          \
+        else KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, false, false>), g, dim3(256), 0, st, p);           \
+        return kalle_check_launch();                                                                                    \
+    } while (0)
+        const int lpt = pick_lpt(Lout, halo, V2_SPAN);
+        if (Cout <= 4) {
+            if (halo + 512 <= V2_SPAN) KALLE_CONV_V2(2, 2, 1, 8, 640);
+        } else if (Cout >= 64 && lpt == 8) {
+            if (ksize == 1) KALLE_CONV_V2(16, 8, 4, 16, 512);   // pointwise conv: longer chunks cover the HBM latency
+            KALLE_CONV_V2(16, 8, 4, 8, 640);
+        } else {
+            switch (lpt) {
+                case 8: KALLE_CONV_V2(8, 8, 4, 8, 640);
+                case 4: KALLE_CONV_V2(8, 4, 4, 8, 640);
+                case 2: KALLE_CONV_V2(8, 2, 4, 8, 640);
+                default: break;
+            }
+        }
+#undef KALLE_CONV_V2
+    }
+    if ((L_T - 1) * stride + halo + 1 > MAX_SPAN) return KALLE_ERR_UNSUPPORTED;
+    dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     if (xf && yf) KALLE_LAUNCH((conv1d_kernel<true, true>), grid, block, 0, st, p);
     else if (xf) KALLE_LAUNCH((conv1d_kernel<true, false>), grid, block, 0, st, p);
     else if (yf) KALLE_LAUNCH((conv1d_kernel<false, true>), grid, block, 0, st, p);
@@ -354,20 +741,52 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
 
 extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                           int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize,
-                                          int stride, int padding, int act, const float* act_alpha,
-                                          const float* act_beta, int act_logscale, float act_param, void* stream) {
+                                          int stride, int padding, const kalle_act* in_act,
+                                          const kalle_conv_epilogue* epi, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lout <= 0) return KALLE_ERR_ARG;
-    if (ksize <= 0 || ksize > MAX_K + 2 || stride <= 0 || padding < 0) return KALLE_ERR_ARG;
-    if (ksize > 2 * stride + 1) return KALLE_ERR_UNSUPPORTED;
+    if (ksize <= 0 || stride <= 0 || padding < 0) return KALLE_ERR_ARG;
     if (Lout > (Lin - 1) * stride - 2 * padding + ksize) return KALLE_ERR_ARG;   // shorter = causal trim of the tail
-    if (act == 1 && (!act_alpha || !act_beta)) return KALLE_ERR_ARG;
-    if (B > 65535 || (Cout + CO_T - 1) / CO_T > 65535) return KALLE_ERR_ARG;
-    if (act == 4) return KALLE_ERR_UNSUPPORTED;
-    ConvParams p{x, w_packed, bias, nullptr, y, B, Cin, Lin, Cout, Lout, ksize, stride, padding, 1, act, 0,
-                 act_alpha, act_beta, act_logscale, act_param, 1.f, Cin};
-    dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
+    if (B > 65535 || (Cout + 7) / 8 > 65535) return KALLE_ERR_ARG;
+    ConvParams p{};
+    if (!fill_params(p, in_act, epi)) return KALLE_ERR_ARG;
+    if (p.act == 4) return KALLE_ERR_UNSUPPORTED;
+    p.x = x; p.w = w_packed; p.bias = bias; p.y = y;
+    p.B = B; p.Cin = Cin; p.Lin = Lin; p.Cout = Cout; p.Lout = Lout; p.K = ksize; p.stride = stride; p.pad = padding;
+    p.dil = 1; p.CoutP = (Cout + 7) & ~7; p.xC = Cin;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
+    const int mmax = (ksize + stride - 1) / stride;
+    if (xf == yf && mmax <= 64 && !getenv("KALLE_CONV_V1")) {
+        const int nq = (Lout - 1 + padding) / stride + 1;      // input positions that reach an output
+#define KALLE_CONVT_V2(COW, LPT, WCO)                                                                                  \
+    do {                                                                                                                \
+        p.ntile = (nq + 64 * LPT * (4 / WCO) - 1) / (64 * LPT * (4 / WCO));                                             \
+        p.nco = (Cout + COW * WCO - 1) / (COW * WCO);                                                                   \
+        const int64_t nwg = (((int64_t)p.ntile * p.nco + 7) / 8) * 8 * stride;                                          \
+        if (nwg > 0x7fffffff) return KALLE_ERR_ARG;                                                                     \
+        dim3 g((unsigned)nwg, 1, B);                                                                                    \
+        if (xf) KALLE_LAUNCH((convT1d_v2_kernel<COW, LPT, WCO, 8, 640, true, true>), g, dim3(256), 0, st, p);           \
+        else KALLE_LAUNCH((convT1d_v2_kernel<COW, LPT, WCO, 8, 640, false, false>), g, dim3(256), 0, st, p);            \
+        return kalle_check_launch();                                                                                    \
+    } while (0)
+        const int lpt = pick_lpt(nq, mmax - 1, V2_SPAN);
+        if (Cout <= 4) {
+            if (mmax - 1 + 512 <= V2_SPAN) KALLE_CONVT_V2(2, 2, 1);
+        } else if (Cout >= 64 && lpt == 8) {
+            KALLE_CONVT_V2(16, 8, 4);
+        } else {
+            switch (lpt) {
+                case 8: KALLE_CONVT_V2(8, 8, 4);
+                case 4: KALLE_CONVT_V2(8, 4, 4);
+                case 2: KALLE_CONVT_V2(8, 2, 4);
+                default: break;
+            }
+        }
+#undef KALLE_CONVT_V2
+    }
+    if (ksize > MAX_K + 2 || ksize > 2 * stride + 1 || p.res || p.post || p.pact || p.out_scale != 1.f)
+        return KALLE_ERR_UNSUPPORTED;
+    dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     if (xf && yf) KALLE_LAUNCH((convT1d_kernel<true, true>), grid, block, 0, st, p);
     else if (xf) KALLE_LAUNCH((convT1d_kernel<true, false>), grid, block, 0, st, p);
     else if (yf) KALLE_LAUNCH((convT1d_kernel<false, true>), grid, block, 0, st, p);

@@ -35,6 +35,13 @@ def _act_args(act):
     raise NotImplementedError(f"activation {type(act).__name__}")
 
 
+def _post_act(act):
+    """descriptor for the conv kernels' OUTPUT activation: the consumer's input activation applied once at the
+    producer's store (instead of once per consumer tile) whenever the raw value has no other reader"""
+    code, a, b, ls = _act_args(act)
+    return None if code == 0 else (code, a, b, ls, 0.0)
+
+
 class _WNBase(nn.Module):
     transposed = False
 
@@ -68,12 +75,12 @@ class WNConv1d(_WNBase):
         self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
 
-    def forward(self, x, act=None, residual=None, post=0):
+    def forward(self, x, act=None, residual=None, post=0, post_act=None):
         x = _prep(x)
         code, a, b, ls = _act_args(act)
         return conv_ops.conv1d(x, self._packed(), self._bias(), Cout=self.out_channels, K=self.kernel_size,
                                stride=self.stride, padding=self.padding, dilation=self.dilation, act=code, alpha=a,
-                               beta=b, logscale=ls, residual=residual, post=post)
+                               beta=b, logscale=ls, residual=residual, post=post, post_act=_post_act(post_act))
 
 
 class WNConvTranspose1d(_WNBase):
@@ -89,12 +96,12 @@ class WNConvTranspose1d(_WNBase):
         self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
 
-    def forward(self, x, act=None):
+    def forward(self, x, act=None, post_act=None):
         x = _prep(x)
         code, a, b, ls = _act_args(act)
         return conv_ops.conv_transpose1d(x, self._packed(), self._bias(), Cout=self.out_channels,
                                          K=self.kernel_size, stride=self.stride, padding=self.padding, act=code,
-                                         alpha=a, beta=b, logscale=ls)
+                                         alpha=a, beta=b, logscale=ls, post_act=_post_act(post_act))
 
 
 def get_activation(activation: Literal["elu", "snake", "none"], antialias=False, channels=None) -> nn.Module:
@@ -112,8 +119,10 @@ def get_activation(activation: Literal["elu", "snake", "none"], antialias=False,
 
 
 class ResidualUnit(nn.Module):
-    """autoencoders.py:39-62: x + conv1(act(conv7_dilated(act(x)))); activations and the residual add are fused
-    into the two conv kernels."""
+    """autoencoders.py:39-62: x + conv1(act(conv7_dilated(act(x)))).  The first activation is applied while the k=7 conv
+    stages its input (x is also needed raw for the skip), the second by the k=7 conv's store (its only reader is the
+    k=1 conv), the residual add by the k=1 conv's store.  `post_act`: the consumer's input activation, folded into the
+    last store when the raw output has no other reader."""
 
     def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
         super().__init__()
@@ -126,10 +135,10 @@ class ResidualUnit(nn.Module):
             get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=out_channels),
             WNConv1d(in_channels=out_channels, out_channels=out_channels, kernel_size=1))
 
-    def forward(self, x):
+    def forward(self, x, post_act=None):
         x = _prep(x)
-        h = self.layers[1](x, act=self.layers[0])
-        return self.layers[3](h, act=self.layers[2], residual=x)
+        h = self.layers[1](x, act=self.layers[0], post_act=self.layers[2])
+        return self.layers[3](h, residual=x, post_act=post_act)
 
 
 class EncoderBlock(nn.Module):
@@ -145,10 +154,11 @@ class EncoderBlock(nn.Module):
             WNConv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=2 * stride, stride=stride,
                      padding=math.ceil(stride / 2)))
 
-    def forward(self, x):
-        for i in range(3):
-            x = self.layers[i](x)
-        return self.layers[4](x, act=self.layers[3])
+    def forward(self, x, post_act=None):
+        x = self.layers[0](x)
+        x = self.layers[1](x)
+        x = self.layers[2](x, post_act=self.layers[3])
+        return self.layers[4](x, post_act=post_act)
 
 
 class DecoderBlock(nn.Module):
@@ -169,11 +179,11 @@ class DecoderBlock(nn.Module):
             ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=3, use_snake=use_snake),
             ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=9, use_snake=use_snake))
 
-    def forward(self, x):
-        x = self.layers[1](x, act=self.layers[0])
-        for i in range(2, 5):
-            x = self.layers[i](x)
-        return x
+    def forward(self, x, pre_activated=False, post_act=None):
+        x = self.layers[1](x, act=None if pre_activated else self.layers[0])
+        x = self.layers[2](x)
+        x = self.layers[3](x)
+        return self.layers[4](x, post_act=post_act)
 
 
 class OobleckEncoder(nn.Module):
@@ -197,8 +207,10 @@ class OobleckEncoder(nn.Module):
         n = len(self.layers)
         x = self.layers[0](x)
         for i in range(1, n - 2):
-            x = self.layers[i](x)
-        return self.layers[n - 1](x, act=self.layers[n - 2])
+            x = self.layers[i](x, post_act=self.layers[n - 2] if i == n - 3 else None)
+        if n == 3:
+            return self.layers[2](x, act=self.layers[1])
+        return self.layers[n - 1](x)
 
 
 class OobleckDecoder(nn.Module):
@@ -224,11 +236,14 @@ class OobleckDecoder(nn.Module):
 
     def forward(self, x):
         n = len(self.layers)
-        x = self.layers[0](x)
+        # every block starts with an activation whose only reader is that block's transposed conv: the producer's
+        # store applies it (layers[i + 1].layers[0] for the next block, layers[n - 3] before the last conv)
+        nxt = lambda i: self.layers[i + 1].layers[0] if i + 1 < n - 3 else self.layers[n - 3]
+        x = self.layers[0](x, post_act=nxt(0))
         for i in range(1, n - 3):
-            x = self.layers[i](x)
+            x = self.layers[i](x, pre_activated=True, post_act=nxt(i))
         post = 1 if isinstance(self.layers[n - 1], nn.Tanh) else 0
-        return self.layers[n - 2](x, act=self.layers[n - 3], post=post)   # tanh fused into the store
+        return self.layers[n - 2](x, post=post)   # tanh fused into the store
 
 
 class AudioAutoencoder(nn.Module):

@@ -356,7 +356,9 @@ def _wn(v, g):
 
 @pytest.mark.parametrize("Cin,Cout,K,stride,dil,L", [(2, 128, 7, 1, 1, 300), (64, 64, 7, 1, 9, 200),
                                                       (64, 128, 4, 2, 1, 257), (128, 64, 16, 8, 1, 512),
-                                                      (96, 40, 3, 1, 1, 77), (32, 32, 1, 1, 1, 130)])
+                                                      (96, 40, 3, 1, 1, 77), (32, 32, 1, 1, 1, 130),
+                                                      (24, 24, 7, 1, 3, 1500), (128, 2, 7, 1, 1, 1300),
+                                                      (20, 1, 7, 1, 1, 515), (9, 17, 11, 1, 5, 700)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_conv1d(ops, dev, Cin, Cout, K, stride, dil, L, act):
     from kalle_audio_amd import conv_ops
@@ -383,7 +385,8 @@ def test_conv1d(ops, dev, Cin, Cout, K, stride, dil, L, act):
     assert rel_l2(y, torch.tanh(r)) < 2e-5
 
 
-@pytest.mark.parametrize("Cin,Cout,stride,L", [(128, 64, 2, 100), (64, 32, 4, 130), (64, 48, 8, 65), (32, 16, 5, 40)])
+@pytest.mark.parametrize("Cin,Cout,stride,L", [(128, 64, 2, 100), (64, 32, 4, 130), (64, 48, 8, 65), (32, 16, 5, 40),
+                                               (24, 40, 4, 700), (16, 2, 2, 1100), (12, 9, 3, 333), (40, 24, 8, 300)])
 def test_conv_transpose1d(ops, dev, Cin, Cout, stride, L):
     from kalle_audio_amd import conv_ops
     B = 2
@@ -464,3 +467,34 @@ def test_conv1d_causal_leaky_gate_scale_accumulate(ops, dev):
     reft = F.conv_transpose1d(x, wt, bias, stride=s)[:, :, :-s]
     gott = conv_ops.conv_transpose1d(x.to(dev), wtp, bias.to(dev), Cout=Cout, K=2 * s, stride=s, padding=0, trim=s)
     assert gott.shape == reft.shape and (gott.cpu() - reft).abs().max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_v1", [False, True])
+def test_conv_post_activation_and_fallback_kernels(ops, dev, force_v1, monkeypatch):
+    """output-side activation (the consumer's input activation applied at the producer's store) for conv and transposed
+    conv, on the main kernels and on the fallback kernels (KALLE_CONV_V1=1)"""
+    from kalle_audio_amd import conv_ops
+    if force_v1:
+        monkeypatch.setenv("KALLE_CONV_V1", "1")
+    torch.manual_seed(11)
+    Bn, Cin, Cout, K, L = 2, 40, 24, 7, 900
+    x = torch.randn(Bn, Cin, L, device=dev)
+    w = torch.randn(Cout, Cin, K, device=dev) / (Cin * K) ** 0.5
+    bias = torch.randn(Cout, device=dev)
+    a, b = 0.3 * torch.randn(Cout, device=dev), 0.3 * torch.randn(Cout, device=dev)
+    res = torch.randn(Bn, Cout, L, device=dev)
+    snake = lambda t: t + torch.sin(t * a.exp()[None, :, None]) ** 2 / (b.exp()[None, :, None] + 1e-9)
+    wp = conv_ops.weight_norm_fold(w, None)
+    ref = snake(F.conv1d(x, w, bias, padding=9, dilation=3) + res)
+    got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, padding=9, dilation=3, residual=res, post_act=(1, a, b, True, 0.0))
+    assert rel_l2(got, ref) < 2e-5
+    ref = F.elu(F.conv1d(x, w, bias, padding=3))
+    got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, padding=3, post_act=(2, None, None, False, 0.0))
+    assert rel_l2(got, ref) < 2e-5
+    if not force_v1:
+        wt = torch.randn(Cin, Cout, 8, device=dev) / (Cin * 2) ** 0.5
+        wtp = conv_ops.weight_norm_fold(wt, None, transposed=True)
+        ref = snake(F.conv_transpose1d(x, wt, bias, stride=4, padding=2))
+        got = conv_ops.conv_transpose1d(x, wtp, bias, Cout=Cout, K=8, stride=4, padding=2, post_act=(1, a, b, True, 0.0))
+        assert rel_l2(got, ref) < 2e-5
