@@ -264,7 +264,11 @@ struct ConvPass {        // one pass of the core = one output phase
     int span;            // slots to stage (<= SPAN)
     int xs0;             // span slot read by tap 0 at local position 0
     int ntaps;           // taps per input channel (K, or the taps of this phase of a transposed conv)
-    int xtap;            // span-slot advance per tap (dilation, or -1)
+    int S;               // input phases of a strided conv (1 otherwise): x index i is staged at LDS slot
+                         // (i - in0) % S * pspan + (i - in0) / S, so a tap reads lane-consecutive slots at any stride
+    int lgS, pspan, ph0; // log2(S), slots per phase row, phase of tap 0
+    int xtap;            // slot advance per tap inside a phase run (S > 1: pspan = next phase)
+    int xtap_wrap;       // slot advance when the phase wraps (S == 1: every tap - the dilation, or -1)
     int64_t w0;          // first weight row of ci = 0, in rows of CoutP
     int64_t wtap, wchan; // weight row advance per tap / from the last tap of ci to the first tap of ci + 1
     int64_t o0;          // output position of local position 0
@@ -342,14 +346,16 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
                 if (sp < g.span) {
                     float v = stg[h][s];
                     if (p.act && ci < p.Cin && li >= 0 && li < p.Lin) v = act_apply(v, p.act, a, inv_b);
-                    Xs[buf * CI + c][sp] = v;
+                    const int slot = g.S == 1 ? sp : (sp & (g.S - 1)) * g.pspan + (sp >> g.lgS);
+                    Xs[buf * CI + c][slot] = v;
                 }
             }
         }
     };
     const cfloat_p wbase = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.w)) + co_w;
     const cfloat_p wlast = wbase + ((int64_t)p.Cin * p.K - 1) * p.CoutP;
-    const int xwrap = SPAN - (g.ntaps - 1) * g.xtap;
+    const int nwrap = (g.ph0 + g.ntaps - 1) / g.S;   // phase wraps among the ntaps-1 advances of one channel
+    const int xwrap = SPAN - ((g.ntaps - 1 - nwrap) * g.xtap + nwrap * g.xtap_wrap);
     const int64_t wtap = g.wtap * p.CoutP, wchan = g.wchan * p.CoutP;
 
     // The scalar weight loads only run one step ahead, so they must hit in L2: every thread touches one 64-B line of the
@@ -398,7 +404,7 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
         cfloat_p wr = wbase + (g.w0 + (int64_t)ci0 * p.K) * p.CoutP;
         if (wr > wlast) wr = wlast;
         const float* xs = &Xs[buf * CI][g.xs0 + wave_l * LW + lane];
-        int kk = 0;
+        int kk = 0, ph = g.ph0;
         f32x2 w0[COW / 2], w1[COW / 2];
         f32x2 x0[LPT / 2], x1[LPT / 2];
         auto ld = [&](f32x2 (&w)[COW / 2], f32x2 (&x)[LPT / 2]) {
@@ -406,7 +412,12 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
             for (int i = 0; i < COW / 2; ++i) w[i] = f32x2{wr[2 * i], wr[2 * i + 1]};
 #pragma unroll
             for (int j = 0; j < LPT / 2; ++j) x[j] = f32x2{xs[128 * j], xs[128 * j + 64]};
-            if (++kk == g.ntaps) { kk = 0; xs += xwrap; wr += wchan; } else { xs += g.xtap; wr += wtap; }
+            if (++kk == g.ntaps) {
+                kk = 0; ph = g.ph0; xs += xwrap; wr += wchan;
+            } else {
+                wr += wtap;
+                if (++ph == g.S) { ph = 0; xs += g.xtap_wrap; } else xs += g.xtap;
+            }
             if (wr > wlast) wr = wlast;              // the one-step-ahead prefetch never leaves the array
         };
         // acc(l_2j, l_2j+1) += w_i * (x_2j, x_2j+1): the weight is one half of an SGPR pair, broadcast by op_sel (hipcc
@@ -469,18 +480,34 @@ __global__ __launch_bounds__(256) void conv1d_v2_kernel(ConvParams p) {
     const int bc = p.co_fast ? blockIdx.x % p.nco : blockIdx.x / p.ntile;
     const int l0 = bt * LT;
     ConvPass g;
-    g.in0 = l0 - p.pad;
-    g.span = (LT - 1) + (p.K - 1) * p.dil + 1;
-    g.xs0 = 0;
     g.ntaps = p.K;
-    g.xtap = p.dil;
     g.w0 = 0;
     g.wtap = 1;
     g.wchan = 1;
     g.o0 = l0;
     g.ostride = 1;
-    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane, wave,
-                                                    wave / WCO);
+    if (p.stride == 1) {
+        g.S = 1; g.lgS = 0; g.pspan = 0; g.ph0 = 0;
+        g.in0 = l0 - p.pad;
+        g.span = (LT - 1) + (p.K - 1) * p.dil + 1;
+        g.xs0 = 0;
+        g.xtap = 0;
+        g.xtap_wrap = p.dil;
+    } else {                                          // power-of-two stride, dilation 1 (host-checked)
+        const int S = p.stride;
+        const int padq = (p.pad + S - 1) / S;         // in0 is a multiple of S: tap k of local position l sits at slot l*S + k + d
+        const int d = padq * S - p.pad;
+        g.S = S; g.lgS = 31 - __builtin_clz(S);
+        g.pspan = LT + 64 / S;                        // (pspan mod 64) = 64/S: the de-interleaving LDS writes are conflict-free
+        g.ph0 = d;
+        g.in0 = (l0 - padq) * S;
+        g.span = (LT - 1) * S + p.K + d;
+        g.xs0 = d * g.pspan;
+        g.xtap = g.pspan;
+        g.xtap_wrap = 1 - (S - 1) * g.pspan;
+    }
+    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane,
+                                                        wave, wave / WCO);
 }
 
 // transposed conv: output lo = q*S + r - pad (phase r < S, input position q):
@@ -508,14 +535,16 @@ __global__ __launch_bounds__(256) void convT1d_v2_kernel(ConvParams p) {
     g.in0 = q0 - (mmax - 1);
     g.span = LT + mmax - 1;
     g.xs0 = mmax - 1;
-    g.xtap = -1;
+    g.S = 1; g.lgS = 0; g.pspan = 0; g.ph0 = 0;
+    g.xtap = 0;
+    g.xtap_wrap = -1;
     g.w0 = r;
     g.wtap = S;
     g.wchan = p.K - (int64_t)(g.ntaps - 1) * S;
     g.o0 = (int64_t)q0 * S + r - p.pad;
     g.ostride = S;
-    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane, wave,
-                                                    wave / WCO);
+    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane,
+                                                        wave, wave / WCO);
 }
 
 // weight norm fold + repack to [Cin][K][CoutP] (CoutP = Cout rounded up to 8, pad columns zeroed). One workgroup per index of dim 0 of v (the weight_norm dim).
@@ -667,17 +696,24 @@ bool fill_params(ConvParams& p, const kalle_act* in_act, const kalle_conv_epilog
     p.pact = pa.code; p.paa = pa.alpha; p.pab = pa.beta; p.plogscale = pa.logscale; p.pparam = pa.param;
     return true;
 }
-// positions-per-lane of the v2 tile: least padded work, slightly favouring the longer (better pipelined) tiles
-int pick_lpt(int64_t npos, int halo, int span) {
-    int best = 0;
+// v2 tile choice: (channels per wave, positions per lane).  A workgroup's cost is its padded output count times a
+// penalty for the shorter (less well pipelined) tiles; workgroups beyond one per CU run in further rounds.
+struct TileChoice { int cow, lpt; };
+TileChoice pick_tile(int64_t npos, int Cout, int B, int halo, int span, int lpt_only, int64_t wg_mult) {
+    const int cows[4] = {16, 8, 8, 8}, lpts[4] = {8, 8, 4, 2};
+    const double pen[4] = {1.0, 1.08, 1.2, 1.5};
+    TileChoice best{0, 0};
     double best_cost = 0;
-    const int lpts[3] = {8, 4, 2};
-    const double pen[3] = {1.0, 1.12, 1.4};
-    for (int i = 0; i < 3; ++i) {
-        const int lt = 64 * lpts[i];
-        if (lt + halo > span) continue;
-        const double cost = (double)((npos + lt - 1) / lt) * lt * pen[i];
-        if (!best || cost < best_cost) { best = lpts[i]; best_cost = cost; }
+    for (int i = 0; i < 4; ++i) {
+        const int lt = 64 * lpts[i], cot = 4 * cows[i];
+        if (lt + halo > span || (lpt_only && lpts[i] != lpt_only)) continue;
+        if (cows[i] == 16 && Cout < 64) continue;
+        const int64_t nwg = ((npos + lt - 1) / lt) * ((Cout + cot - 1) / cot) * B * wg_mult;
+        // rounds: 2 (COW 16) / 3 (COW 8) workgroups fit a CU; a lone workgroup per CU still costs ~0.6 of a full round
+        const int64_t slots = 256 * (cows[i] == 16 ? 2 : 3);
+        const double rounds = nwg <= 256 ? 0.6 : (double)((nwg + slots - 1) / slots);
+        const double cost = (double)lt * cot * pen[i] * rounds * (cows[i] == 16 ? 2 : 3);
+        if (!best.cow || cost < best_cost) { best = TileChoice{cows[i], lpts[i]}; best_cost = cost; }
     }
     return best;
 }
@@ -703,7 +739,8 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     const int halo = (ksize - 1) * dilation;
     // weights small enough to stay in one XCD's L2: run the channel tiles of a position tile back to back (x re-read hits L2)
     p.co_fast = (int64_t)Cin * ksize * p.CoutP * 4 <= (2 << 20);
-    if (stride == 1 && p.act != 4 && xf == yf && !getenv("KALLE_CONV_V1")) {
+    const bool v2_stride = stride == 1 || (dilation == 1 && (stride == 2 || stride == 4 || stride == 8) && ksize <= 32);
+    if (v2_stride && p.act != 4 && xf == yf && !getenv("KALLE_CONV_V1")) {
 #define KALLE_CONV_V2(COW, LPT, WCO, CI, SPAN)                                                                         \
     do {                                                                                                                \
         p.ntile = (Lout + 64 * LPT * (4 / WCO) - 1) / (64 * LPT * (4 / WCO));                                          \
@@ -714,19 +751,25 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
         else KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, false, false>), g, dim3(256), 0, st, p);           \
         return kalle_check_launch();                                                                                    \
     } while (0)
-        const int lpt = pick_lpt(Lout, halo, V2_SPAN);
-        if (Cout <= 4) {
-            if (halo + 512 <= V2_SPAN) KALLE_CONV_V2(2, 2, 1, 8, 640);
-        } else if (Cout >= 64 && lpt == 8) {
-            if (ksize == 1) KALLE_CONV_V2(16, 8, 4, 16, 512);   // pointwise conv: longer chunks cover the HBM latency
-            KALLE_CONV_V2(16, 8, 4, 8, 640);
-        } else {
-            switch (lpt) {
-                case 8: KALLE_CONV_V2(8, 8, 4, 8, 640);
-                case 4: KALLE_CONV_V2(8, 4, 4, 8, 640);
-                case 2: KALLE_CONV_V2(8, 2, 4, 8, 640);
-                default: break;
+        if (stride == 1) {
+            const TileChoice tc = pick_tile(Lout, Cout, B, halo, V2_SPAN, 0, 1);
+            if (Cout <= 4) {
+                if (halo + 512 <= V2_SPAN) KALLE_CONV_V2(2, 2, 1, 8, 640);
+            } else if (tc.cow == 16) {
+                if (ksize == 1) KALLE_CONV_V2(16, 8, 4, 16, 512);   // pointwise conv: longer chunks cover the HBM latency
+                KALLE_CONV_V2(16, 8, 4, 8, 640);
+            } else {
+                switch (tc.lpt) {
+                    case 8: KALLE_CONV_V2(8, 8, 4, 8, 640);
+                    case 4: KALLE_CONV_V2(8, 4, 4, 8, 640);
+                    case 2: KALLE_CONV_V2(8, 2, 4, 8, 640);
+                    default: break;
+                }
             }
+        } else if (Cout > 4) {                           // stride 2 / 4 / 8: de-interleaved staging, 1024/stride positions
+            if (stride == 2) KALLE_CONV_V2(8, 8, 4, 8, 1088);
+            if (stride == 4) KALLE_CONV_V2(8, 4, 4, 8, 1088);
+            if (stride == 8 && (int64_t)Lout * B <= 1024) KALLE_CONV_V2(8, 2, 4, 8, 1088);   // longer: fallback kernel is faster
         }
 #undef KALLE_CONV_V2
     }
@@ -769,13 +812,13 @@ extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const floa
         else KALLE_LAUNCH((convT1d_v2_kernel<COW, LPT, WCO, 8, 640, false, false>), g, dim3(256), 0, st, p);            \
         return kalle_check_launch();                                                                                    \
     } while (0)
-        const int lpt = pick_lpt(nq, mmax - 1, V2_SPAN);
+        const TileChoice tc = pick_tile(nq, Cout, B, mmax - 1, V2_SPAN, 0, stride);
         if (Cout <= 4) {
             if (mmax - 1 + 512 <= V2_SPAN) KALLE_CONVT_V2(2, 2, 1);
-        } else if (Cout >= 64 && lpt == 8) {
+        } else if (tc.cow == 16) {
             KALLE_CONVT_V2(16, 8, 4);
         } else {
-            switch (lpt) {
+            switch (tc.lpt) {
                 case 8: KALLE_CONVT_V2(8, 8, 4);
                 case 4: KALLE_CONVT_V2(8, 4, 4);
                 case 2: KALLE_CONVT_V2(8, 2, 4);

@@ -358,7 +358,9 @@ def _wn(v, g):
                                                       (64, 128, 4, 2, 1, 257), (128, 64, 16, 8, 1, 512),
                                                       (96, 40, 3, 1, 1, 77), (32, 32, 1, 1, 1, 130),
                                                       (24, 24, 7, 1, 3, 1500), (128, 2, 7, 1, 1, 1300),
-                                                      (20, 1, 7, 1, 1, 515), (9, 17, 11, 1, 5, 700)])
+                                                      (20, 1, 7, 1, 1, 515), (9, 17, 11, 1, 5, 700),
+                                                      (24, 40, 8, 4, 1, 2100), (16, 72, 4, 2, 1, 3001),
+                                                      (10, 24, 16, 8, 1, 2500), (8, 8, 6, 2, 1, 130)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_conv1d(ops, dev, Cin, Cout, K, stride, dil, L, act):
     from kalle_audio_amd import conv_ops

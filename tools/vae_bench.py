@@ -50,14 +50,16 @@ if "--layers" in sys.argv:
             return y
         return inner
     conv_ops.conv1d, conv_ops.conv_transpose1d = wrap(conv_ops.conv1d, "conv"), wrap(conv_ops.conv_transpose1d, "convT")
+    which = "encode" if "--encode" in sys.argv else "decode"
     with torch.no_grad():
-        ae.decode(z)
+        ae.encode(wav) if which == "encode" else ae.decode(z)
     torch.cuda.synchronize()
     out = []
     for r in rec:
         ms = r["ev"][0].elapsed_time(r["ev"][1])
         out.append({k: v for k, v in r.items() if k != "ev"} | {"us": ms * 1e3, "GBps": r["bytes"] / ms / 1e6,
                                                                 "TFLOPs": r["flops"] / ms / 1e9})
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "vae_layers.json"), "w"))
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out",
+                                     f"vae_layers_{which}.json" if which == "encode" else "vae_layers.json"), "w"))
     tot_t = sum(o["us"] for o in out); tot_f = sum(o["flops"] for o in out); tot_b = sum(o["bytes"] for o in out)
-    print(f"decode B={B}: {len(out)} conv launches, {tot_t/1e3:.1f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s, {tot_b/tot_t/1e3:.0f} GB/s algorithmic")
+    print(f"{which} B={B}: {len(out)} conv launches, {tot_t/1e3:.1f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s, {tot_b/tot_t/1e3:.0f} GB/s algorithmic")
