@@ -106,9 +106,11 @@ int kalle_adaln_mod_bwd(const void* dy, const void* x, int x_dtype, const float*
 /* RMSNorm  y = x * scale * rsqrt(mean(x^2)+eps)   (blocks.py:268-272, 285-299; AdaRMSNorm 211-221 via scale=[b]) */
 int kalle_rmsnorm_fwd(const void* x, int x_dtype, const float* scale, int64_t ld_scale, int rows_per_batch,
                       void* y, int y_dtype, float* rrms, int rows, int D, float eps, void* stream);
+/* dx = RMSNorm backward (+ dres, the residual-stream gradient, when given); dx_bf16: optional bf16 copy of dx for the
+ * next GEMM (the Llama decoder layers under model_sigmaVAE.py:78-81: input_layernorm / post_attention_layernorm) */
 int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale, int64_t ld_scale,
-                      int rows_per_batch, const float* rrms, float* dx, float* dscale_part, int rows, int D,
-                      void* stream);
+                      int rows_per_batch, const float* rrms, float* dx, float* dscale_part, const float* dres,
+                      void* dx_bf16, int rows, int D, void* stream);
 
 /* column sums: out[c] (+)= sum_r in[r][c]; in fp32 or bf16 [rows][ld]. Used for bias grads and partial reduces. */
 int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out, int rows, int cols, int accumulate,
@@ -177,26 +179,28 @@ int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w
                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Attention (non-causal, optional key mask), LDS-resident K/V tiles, bf16 MFMA, fp32 softmax.
+ * Attention (optional causal mask, optional key mask), LDS-resident K/V tiles, bf16 MFMA, fp32 softmax.
  *   out[b, i, h*64+d] = softmax_j(q_i . k_j / 8 + maskbias_j) v_j              (transformer.py:382-387, 494, 514-530)
  * q/k/v are read in place from the projection outputs (no head transposes):
  *   q: [B][Nq][ldq]  head h at column q_off + h*64 ; k: [B][Nk][ldk] at k_off + (h / (H/Hkv))*64 ; v likewise
  *   (self-attention: q,k,v all point into the fused to_qkv output, ld = 3*D, offsets 0, D, 2D;
  *    cross-attention: q from to_q (ld=D), k/v from to_kv output (ld=2*Dc, offsets 0, Dc); GQA repeat_interleave 337-340)
- * rope_cos/rope_sin: [Npos][rot/2] fp32 tables or NULL - partial rotary on the first `rot` dims of q and k
- *   (transformer.py:146-170, 430-444), applied on the fly.
+ * rope_cos/rope_sin: [Npos][rot/2] fp32 tables or NULL - rotary on the first `rot` dims of q and k, applied on the fly:
+ *   rot = 32 the DiT's partial rotary (transformer.py:146-170, 430-444), rot = 64 the Llama decoder's (HF
+ *   `apply_rotary_pos_emb`, the third-party model under model_sigmaVAE.py:17-29).
+ * causal != 0: query i attends keys j <= i + (Nk - Nq) only (the Llama decoder called at model_sigmaVAE.py:78-81).
  * key_mask: uint8 [B][Nk] (1 = attend) or NULL.  lse: [B][H][Nq] fp32 saved for backward.  head dim fixed at 64.
  */
 int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
                         const void* v, int64_t ldv, int v_off, void* out, int64_t ldo, float* lse,
-                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask, int causal,
                         int B, int H, int Hkv, int Nq, int Nk, void* stream);
 /* backward: dq/dk/dv written with the same strides/offsets into dq_buf/dk_buf/dv_buf (bf16). For GQA dk/dv are
  * summed over the query heads sharing a kv head; RoPE is un-rotated on dq/dk. delta scratch: [B][H][Nq] fp32. */
 int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
                         const void* v, int64_t ldv, int v_off, const void* out, const void* dout, int64_t ldo,
                         const float* lse, float* delta, void* dq, void* dk, void* dv,
-                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
+                        const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask, int causal,
                         int B, int H, int Hkv, int Nq, int Nk, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -255,6 +259,31 @@ int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const fl
 int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
                                int padding, const kalle_act* in_act, const kalle_conv_epilogue* epi, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Llasa task model head / tail (model_sigmaVAE.py:53-104); the Llama decoder layers in between run on kalle_gemm_bf16,
+ * kalle_rmsnorm_*, kalle_attention_* (causal, rot = 64, GQA).
+ */
+/* out = a x + b y, fp32   (fixed-sigma sampling x = mean + std * randn, model_sigmaVAE.py:150-166) */
+int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream);
+/* out[r, :] = audio[r, :] * audio_mask[r] + table[ids[r], :] * ids_mask[r]   (embed_tokens + masked mix, :66-73);
+ * table fp32 [vocab][D], audio fp32 or bf16 [rows][D], masks fp32 [rows], out fp32 */
+int kalle_embed_mix_fwd(const int64_t* ids, const float* table, const void* audio, int audio_dtype, const float* ids_mask,
+                        const float* audio_mask, float* out, int64_t rows, int D, int64_t vocab, void* stream);
+/* daudio = dout * audio_mask (if daudio); dtable[ids[r], :] += dout[r, :] * ids_mask[r] (if dtable; fp32 atomics) */
+int kalle_embed_mix_bwd(const float* dout, const int64_t* ids, const float* ids_mask, const float* audio_mask,
+                        float* dtable, float* daudio, int64_t rows, int D, int64_t vocab, void* stream);
+/* exact (erf) GELU, nn.GELU() default (model_sigmaVAE.py:46) */
+int kalle_gelu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
+int kalle_gelu_bwd(const void* dy, const void* x, void* dx, int dtype, int64_t n, void* stream);
+/* masked fixed-sigma Gaussian KL (model_sigmaVAE.py:85-95): kl[r] = sum_c (pred - label)^2 / (2 std^2) / dim;
+ * sums4 (zeroed by the caller) += {sum kl*mask_a, sum mask_a, sum kl*mask_b, sum mask_b}; the two losses are
+ * sums4[0]/sums4[1] and sums4[2]/sums4[3].  bwd: dpred for upstream gradients grad_a / grad_b (device scalars). */
+int kalle_gauss_kl_fwd(const float* pred, const float* label, const float* mask_a, const float* mask_b, float* sums4,
+                       float std, int64_t rows, int dim, void* stream);
+int kalle_gauss_kl_bwd(const float* pred, const float* label, const float* mask_a, const float* mask_b,
+                       const float* sums4, const float* grad_a, const float* grad_b, float* dpred, float std,
+                       int64_t rows, int dim, void* stream);
+
 /* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
  * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)
  * -> 2x FIR low-pass downsample.  x, y: (B, C, L) fp32 or bf16; filter12: the 12 fp32 taps. */

@@ -1,4 +1,5 @@
-// Fused attention for the DiT block (gfx950), forward and backward, head dim 64, non-causal.
+// Fused attention for the DiT block and the Llama decoder layers (gfx950), forward and backward, head dim 64,
+// optional causal mask (keys j <= i + Nk - Nq), optional key-padding mask, rotary on the first 32 or on all 64 dims.
 // Reference: stable_audio_tools/models/transformer.py:396-547 (Attention.forward: rotary 430-444, key mask 446-462,
 // softmax(QK^T/sqrt(d))V 502-530 / SDPA 382-387, GQA repeat_interleave 337-340, 505-508) and
 // transformer.py:146-170 (rotate_half / apply_rotary_pos_emb, partial rotary on the first 32 dims).
@@ -23,7 +24,8 @@ constexpr int AT_TILE = 128 * AT_STRIDE;   // 20480 B
 constexpr float SM_SCALE = 0.125f;         // 1/sqrt(64)
 constexpr float NEG_BIG = -1.0e30f;
 
-// stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying partial rotary (rot==32)
+// stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying rotary on the first `rot`
+// (32: DiT partial rotary; 64: Llama) dims: out = x cos + rotate_half(x) sin, tables [pos][rot/2]
 template <int NT>
 __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
@@ -36,13 +38,14 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t
         if (row < nvalid) {
             const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
             v = *reinterpret_cast<const i32x4*>(rp + 8 * c);
-            if (rot && c < 4) {
-                const i32x4 pv = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ 2));
-                const float* cp = cosT + (int64_t)(row0 + row) * 16 + (c & 1) * 8;
-                const float* sp = sinT + (int64_t)(row0 + row) * 16 + (c & 1) * 8;
+            const int hc = rot >> 4;                    // 8-element chunks per rotary half (2 or 4)
+            if (rot && c < 2 * hc) {
+                const i32x4 pv = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ hc));
+                const float* cp = cosT + (int64_t)(row0 + row) * (rot >> 1) + (c & (hc - 1)) * 8;
+                const float* sp = sinT + (int64_t)(row0 + row) * (rot >> 1) + (c & (hc - 1)) * 8;
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                const float sg = (c < 2) ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
+                const float sg = (c < hc) ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -104,6 +107,7 @@ struct AttnParams {
     const float* cosT; const float* sinT; int rot;
     const uint8_t* mask;
     int B, H, Hkv, Nq, Nk;
+    int causal;          // keys j <= i + (Nk - Nq) only
     // backward only
     const bf16_t* dout; const float* delta;
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
@@ -147,7 +151,9 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < p.Nk; k0 += 128) {
+    const int coff = p.Nk - p.Nq;                      // causal: query i sees keys j <= i + coff
+    const int kend = p.causal ? min(p.Nk, q0 + 128 + coff) : p.Nk;
+    for (int k0 = 0; k0 < kend; k0 += 128) {
         __syncthreads();  // previous block's K/V reads are done
         const int kval = min(128, p.Nk - k0);
         stage_tile<NT>(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
@@ -186,6 +192,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                 for (int r = 0; r < 4; ++r) {
                     float sv = acc[kt][qt][r] * SM_SCALE;
                     sv = (kb[r] == 0.f) ? sv : kb[r];
+                    if (p.causal && k0 + 16 * kt + 4 * g + r > q0 + wave * (16 * QT) + 16 * qt + li + coff)
+                        sv = fminf(sv, NEG_BIG);
                     acc[kt][qt][r] = sv;
                     mx[qt] = fmaxf(mx[qt], sv);
                 }
@@ -350,9 +358,13 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
 
     const int nstream = KV ? p.Nq : p.Nk;
     const int nheads = KV ? group : 1;
+    const int coff = p.Nk - p.Nq;
     for (int hh = 0; hh < nheads; ++hh) {
         const int hq = KV ? hk * group + hh : hown;
         for (int s0 = 0; s0 < nstream; s0 += 128) {
+            if (p.causal) {   // whole streamed block on the masked side of the diagonal (uniform per workgroup)
+                if (KV ? (s0 + 127 + coff < o0) : (s0 > o0 + 127 + coff)) continue;
+            }
             __syncthreads();  // previous tile fully consumed (also guards the owner-fragment reads)
             const int sval = min(128, nstream - s0);
             if constexpr (KV) {
@@ -407,12 +419,16 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float pv, dl;
+                            const int si = s0 + rb + 4 * g + r;                          // streamed index
+                            const int oi = o0 + wave * (16 * OT) + 16 * ot + li;         // owner index
                             if constexpr (KV) {
                                 pv = ca[ot] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ra[r]) : 0.f;
                                 dl = rbv[r];
+                                if (p.causal && oi > si + coff) pv = 0.f;                // key > query
                             } else {
                                 pv = ra[r] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ca[ot]) : 0.f;
                                 dl = cb[ot];
+                                if (p.causal && si > oi + coff) pv = 0.f;
                             }
                             sa[t][ot][r] = pv;
                             dp[t][ot][r] = pv * (dp[t][ot][r] - dl) * SM_SCALE;
@@ -448,13 +464,20 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
         const int oi = o0 + wave * (16 * OT) + 16 * ot + li;
         if (oi >= nown) continue;
         if (p.rot) {
-            const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * 16 + 4 * g);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + (int64_t)oi * 16 + 4 * g);
+            const int hts = p.rot >> 5;                 // 16-dim tiles per rotary half (1 or 2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = g2[0][ot][r], bb = g2[1][ot][r];
-                g2[0][ot][r] = a * c4[r] + bb * s4[r];
-                g2[1][ot][r] = bb * c4[r] - a * s4[r];
+            for (int ht = 0; ht < 2; ++ht) {
+                if (ht >= hts) break;
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
+                f32x4& lo = hts == 1 ? g2[0][ot] : g2[ht][ot];
+                f32x4& hi = hts == 1 ? g2[1][ot] : g2[ht + 2][ot];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = lo[r], bb = hi[r];
+                    lo[r] = a * c4[r] + bb * s4[r];
+                    hi[r] = bb * c4[r] - a * s4[r];
+                }
             }
         }
         if constexpr (KV) {
@@ -488,7 +511,7 @@ bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t 
     if (!q || !k || !v || B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) return false;
     if (H % Hkv) return false;
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (q_off & 7) || (k_off & 7) || (v_off & 7)) return false;
-    if (rot != 0 && rot != 32) return false;
+    if (rot != 0 && rot != 32 && rot != 64) return false;
     if (H > 65535 || B > 65535) return false;
     return true;
 }
@@ -498,7 +521,7 @@ bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t 
 extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
                                    const void* v, int64_t ldv, int v_off, void* out, int64_t ldo, float* lse,
                                    const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
-                                   int B, int H, int Hkv, int Nq, int Nk, void* stream) {
+                                   int causal, int B, int H, int Hkv, int Nq, int Nk, void* stream) {
     if (!out || !check_common(q, ldq, q_off, k, ldk, k_off, v, ldv, v_off, ldo, rot, B, H, Hkv, Nq, Nk))
         return KALLE_ERR_ARG;
     if (rot && (!rope_cos || !rope_sin)) return KALLE_ERR_ARG;
@@ -508,7 +531,8 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
     p.v = static_cast<const bf16_t*>(v); p.ldv = ldv; p.v_off = v_off;
     p.out = static_cast<bf16_t*>(out); p.ldo = ldo; p.lse = lse;
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
-    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
+    if (causal && Nk < Nq) return KALLE_ERR_ARG;
     constexpr int lds = 3 * AT_TILE + 128 * 4;
     static bool attr = false;
     if (!attr) {
@@ -524,7 +548,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
                                    const void* v, int64_t ldv, int v_off, const void* out, const void* dout,
                                    int64_t ldo, const float* lse, float* delta, void* dq, void* dk, void* dv,
                                    const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
-                                   int B, int H, int Hkv, int Nq, int Nk, void* stream) {
+                                   int causal, int B, int H, int Hkv, int Nq, int Nk, void* stream) {
     if (!out || !dout || !lse || !delta || !dq || !dk || !dv ||
         !check_common(q, ldq, q_off, k, ldk, k_off, v, ldv, v_off, ldo, rot, B, H, Hkv, Nq, Nk))
         return KALLE_ERR_ARG;
@@ -536,7 +560,8 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.v = static_cast<const bf16_t*>(v); p.ldv = ldv; p.v_off = v_off;
     p.out = nullptr; p.ldo = ldo; p.lse = const_cast<float*>(lse);
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
-    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk;
+    p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
+    if (causal && Nk < Nq) return KALLE_ERR_ARG;
     p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 

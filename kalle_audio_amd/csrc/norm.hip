@@ -266,7 +266,8 @@ template <int NCH, bool XF32, bool DYF32>
 __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                       const float* __restrict__ scale, int64_t ld_scale, int rpb,
                                                       const float* __restrict__ rrms, float* __restrict__ dx,
-                                                      float* __restrict__ dsp, int rows, int D) {
+                                                      float* __restrict__ dsp, const float* __restrict__ dres,
+                                                      bf16_t* __restrict__ dxb, int rows, int D) {
     __shared__ float red[4][64 * 8 + 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float as[NCH][8];
@@ -304,7 +305,14 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = dh[j][e] * rr - xv[j][e] * c;
+                if (dres) {   // fused residual-stream gradient add
+                    float rsd[8];
+                    load8<true>(dres, (int64_t)row * D + col, rsd);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += rsd[e];
+                }
                 store8<true>(dx, (int64_t)row * D + col, o);
+                if (dxb) store8<false>(dxb, (int64_t)row * D + col, o);
             }
         }
     }
@@ -460,7 +468,8 @@ extern "C" int kalle_rmsnorm_fwd(const void* x, int x_dtype, const float* scale,
 
 extern "C" int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale,
                                  int64_t ld_scale, int rows_per_batch, const float* rrms, float* dx,
-                                 float* dscale_part, int rows, int D, void* stream) {
+                                 float* dscale_part, const float* dres, void* dx_bf16, int rows, int D,
+                                 void* stream) {
     if (!dy || !x || !scale || !rrms || !dx || rows <= 0 || D <= 0 || (D & 7) || D > 4096) return KALLE_ERR_ARG;
     const int rpb = rows_per_batch > 0 ? rows_per_batch : rows;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -468,16 +477,16 @@ extern "C" int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, in
 #define CALL(N)                                                                                                     \
     if (x_dtype == KALLE_F32 && dy_dtype == KALLE_F32)                                                              \
         KALLE_LAUNCH((rms_bwd_kernel<N, true, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms,  \
-                           dx, dscale_part, rows, D);                                                               \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
     else if (x_dtype == KALLE_F32)                                                                                  \
         KALLE_LAUNCH((rms_bwd_kernel<N, true, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
-                           dx, dscale_part, rows, D);                                                               \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
     else if (dy_dtype == KALLE_F32)                                                                                 \
         KALLE_LAUNCH((rms_bwd_kernel<N, false, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
-                           dx, dscale_part, rows, D);                                                               \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
     else                                                                                                            \
         KALLE_LAUNCH((rms_bwd_kernel<N, false, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb,      \
-                           rrms, dx, dscale_part, rows, D);
+                           rrms, dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);
     DISPATCH_NCH(D, CALL);
 #undef CALL
     return kalle_check_launch();

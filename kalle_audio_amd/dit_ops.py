@@ -82,6 +82,15 @@ class GradOut:
         self.grads[name] = None if s is not None else dgamma
         return dx, dxb
 
+    def rms(self, name, dy, x, scale, rrms, dres=None, dx_bf16=None):
+        """RMSNorm backward (+ residual-stream gradient, + bf16 copy): returns dx fp32; dscale to the sink / grads."""
+        s = self._sink(name)
+        dx, dscale = ops.rmsnorm_bwd(dy, x, scale, rrms, dres=dres, dx_bf16=dx_bf16,
+                                     dscale_out=s.view(-1) if s is not None else None,
+                                     accumulate=self.accumulate if s is not None else False)
+        self.grads[name] = None if s is not None else dscale
+        return dx
+
     def bias_acc(self, name, n, device):
         """fp32 [n] buffer a kernel atomically ADDS a bias gradient into (zeroed first unless accumulating)."""
         s = self._sink(name)

@@ -124,8 +124,8 @@ class FlatBuckets:
 
 
 class DataParallelTrainer:
-    """Owns flat buffers, bucketed gradient all-reduce and the fused optimizer for a DiT (any module tree whose
-    TransformerBlocks come from kalle_audio_amd.stable_audio_tools.models.transformer)."""
+    """Owns flat buffers, bucketed gradient all-reduce and the fused optimizer for a DiT or the Llasa task model (any
+    module tree whose repeated layers are this package's TransformerBlock / LlamaDecoderLayer: one bucket each)."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="Adam",
                  grad_accum_steps=1, lr_schedule=None, process_group=None, comm_dtype=torch.float32):
@@ -144,7 +144,8 @@ class DataParallelTrainer:
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         device = named[0][1].device
         # bucket key: the owning TransformerBlock's module path, or "_rest"
-        self.blocks = [(n, m) for n, m in model.named_modules() if isinstance(m, TransformerBlock)]
+        self.blocks = [(n, m) for n, m in model.named_modules()
+                       if isinstance(m, TransformerBlock) or getattr(m, "_kalle_bucket_unit", False)]
         prefixes = [n + "." for n, _ in self.blocks]
 
         def bucket_of(name):
@@ -167,6 +168,10 @@ class DataParallelTrainer:
             blk._kalle_grad_accumulate = False
             blk._kalle_bucket_key = pre
             blk._kalle_on_backward_done = self._on_block_done
+        # large tables whose backward scatter-adds straight into the flat gradient (token embeddings)
+        for n, p in named:
+            if getattr(p, "_kalle_wants_sink", False) and bucket_of(n) == "_rest":
+                p._kalle_grad_sink = self.flat.grad_view(n)
 
     # -- gradient communication ---------------------------------------------------------------------------
     def _allreduce(self, buf):

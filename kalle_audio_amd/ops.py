@@ -165,7 +165,8 @@ def rmsnorm_fwd(x, scale, rows_per_batch=0, eps=1e-6, out_dtype=None):
     return y, rrms
 
 
-def rmsnorm_bwd(dy, x, scale, rrms, rows_per_batch=0):
+def rmsnorm_bwd(dy, x, scale, rrms, rows_per_batch=0, dres=None, dx_bf16=None, dscale_out=None, accumulate=False):
+    """returns (dx fp32 [+ dres], dscale) - dscale is written / accumulated into `dscale_out` when given"""
     lib = _lib.load()
     rows, D = _rows2d(x)
     dy = dy.contiguous()
@@ -174,7 +175,10 @@ def rmsnorm_bwd(dy, x, scale, rrms, rows_per_batch=0):
     dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     ld = scale.stride(-2) if scale.dim() >= 2 else 0
     check(lib.kalle_rmsnorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(scale), ld, rows_per_batch, _p(rrms), _p(dx),
-                                _p(dsp), rows, D, _stream()), "kalle_rmsnorm_bwd")
+                                _p(dsp), _p(dres), _p(dx_bf16), rows, D, _stream()), "kalle_rmsnorm_bwd")
+    if dscale_out is not None:
+        colsum(dsp, out=dscale_out, accumulate=accumulate)
+        return dx, None
     return dx, colsum(dsp)
 
 
@@ -324,7 +328,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, param_bf16, *, lr, beta1=0.9, be
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention_fwd(q, k, v, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq, Nk, rope=None, key_mask=None):
+def attention_fwd(q, k, v, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq, Nk, rope=None, key_mask=None,
+                  causal=False):
     """q/k/v: base tensors (bf16) of the projection outputs; see kalle_attention_fwd. Returns (out [B,Nq,H*64], lse)."""
     lib = _lib.load()
     out = torch.empty((B, Nq, H * 64), device=q.device, dtype=torch.bfloat16)
@@ -332,16 +337,83 @@ def attention_fwd(q, k, v, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq,
     cos, sin, rot = (rope[0], rope[1], rope[0].shape[-1] * 2) if rope is not None else (None, None, 0)
     m8 = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
     check(lib.kalle_attention_fwd(_p(q), ldq, q_off, _p(k), ldk, k_off, _p(v), ldv, v_off, _p(out), H * 64, _p(lse),
-                                  _p(cos), _p(sin), rot, _p(m8), B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_fwd")
+                                  _p(cos), _p(sin), rot, _p(m8), int(causal), B, H, Hkv, Nq, Nk, _stream()),
+          "kalle_attention_fwd")
     return out, lse
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, ldq, q_off, ldk, k_off, ldv, v_off, B, H, Hkv, Nq, Nk,
-                  rope=None, key_mask=None):
+                  rope=None, key_mask=None, causal=False):
     lib = _lib.load()
     delta = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
     cos, sin, rot = (rope[0], rope[1], rope[0].shape[-1] * 2) if rope is not None else (None, None, 0)
     m8 = key_mask.to(torch.uint8).contiguous() if key_mask is not None else None
     check(lib.kalle_attention_bwd(_p(q), ldq, q_off, _p(k), ldk, k_off, _p(v), ldv, v_off, _p(out), _p(dout), H * 64,
                                   _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(cos), _p(sin), rot, _p(m8),
-                                  B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_bwd")
+                                  int(causal), B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ Llasa head / tail
+def axpby(x, y, a, b):
+    lib = _lib.load()
+    x, y = x.contiguous(), y.contiguous()
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape
+    out = torch.empty_like(x)
+    check(lib.kalle_axpby(_p(x), _p(y), _p(out), float(a), float(b), x.numel(), _stream()), "kalle_axpby")
+    return out
+
+
+def embed_mix_fwd(ids, table, audio, ids_mask, audio_mask):
+    """ids [rows] int64, table fp32 [V, D], audio fp32/bf16 [rows, D], masks fp32 [rows] -> fp32 [rows, D]"""
+    lib = _lib.load()
+    rows, D = audio.shape
+    out = torch.empty((rows, D), device=audio.device, dtype=torch.float32)
+    check(lib.kalle_embed_mix_fwd(_p(ids), _p(table), _p(audio), _dt(audio), _p(ids_mask), _p(audio_mask), _p(out), rows, D,
+                                  table.shape[0], _stream()), "kalle_embed_mix_fwd")
+    return out
+
+
+def embed_mix_bwd(dout, ids, ids_mask, audio_mask, dtable=None, want_daudio=True):
+    lib = _lib.load()
+    rows, D = dout.shape
+    daudio = torch.empty((rows, D), device=dout.device, dtype=torch.float32) if want_daudio else None
+    V = dtable.shape[0] if dtable is not None else 1
+    check(lib.kalle_embed_mix_bwd(_p(dout), _p(ids), _p(ids_mask), _p(audio_mask), _p(dtable), _p(daudio), rows, D, V,
+                                  _stream()), "kalle_embed_mix_bwd")
+    return daudio
+
+
+def gelu_fwd(x):
+    lib = _lib.load()
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.kalle_gelu_fwd(_p(x), _p(y), _dt(x), x.numel(), _stream()), "kalle_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    lib = _lib.load()
+    dy = dy.contiguous()
+    assert dy.dtype == x.dtype
+    dx = torch.empty_like(x)
+    check(lib.kalle_gelu_bwd(_p(dy), _p(x), _p(dx), _dt(x), x.numel(), _stream()), "kalle_gelu_bwd")
+    return dx
+
+
+def gauss_kl_fwd(pred, label, mask_a, mask_b, std):
+    """returns sums4 = [sum kl*ma, sum ma, sum kl*mb, sum mb] (fp32, device)"""
+    lib = _lib.load()
+    rows, d = pred.shape
+    sums = torch.zeros(4, device=pred.device, dtype=torch.float32)
+    check(lib.kalle_gauss_kl_fwd(_p(pred), _p(label), _p(mask_a), _p(mask_b), _p(sums), float(std), rows, d, _stream()),
+          "kalle_gauss_kl_fwd")
+    return sums
+
+
+def gauss_kl_bwd(pred, label, mask_a, mask_b, sums, grad_a, grad_b, std):
+    lib = _lib.load()
+    rows, d = pred.shape
+    dpred = torch.empty_like(pred)
+    check(lib.kalle_gauss_kl_bwd(_p(pred), _p(label), _p(mask_a), _p(mask_b), _p(sums), _p(grad_a), _p(grad_b), _p(dpred),
+                                 float(std), rows, d, _stream()), "kalle_gauss_kl_bwd")
+    return dpred

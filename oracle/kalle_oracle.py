@@ -657,3 +657,82 @@ def melvae_forward(sd, wav, eps, h):
     z = m_q + eps * torch.exp(logs_q)
     z_p = residual_coupling_block(_sub(sd, "flow."), z, causal=h["causal"])
     return melvae_decode(sd, z, h), z_p, logs_q
+
+
+# ---------------------------------------------------------------------------------------------- Llasa (model_sigmaVAE.py)
+# The decoder under Llasa is third-party: `transformers` LlamaModel (version unpinned by the reference; 5.15.0 here),
+# restated below from its published algorithm (pre-norm decoder: RMSNorm, rotary over the whole head, grouped-query causal
+# attention, SwiGLU MLP, final RMSNorm; llama3 rope scaling).  PINNED by tests/golden/llasa.npz (reference Llasa run over
+# a tiny locally-built Llama).
+def llama_inv_freq(head_dim, theta, scaling=None):
+    """rope frequencies incl. the 'llama3' scaling rule (long wavelengths / factor, smooth blend in the medium band)"""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    if not scaling or scaling.get("rope_type", scaling.get("type")) in (None, "default"):
+        return inv
+    assert scaling.get("rope_type", scaling.get("type")) == "llama3"
+    factor, lo, hi = scaling["factor"], scaling["low_freq_factor"], scaling["high_freq_factor"]
+    old = scaling["original_max_position_embeddings"]
+    wavelen = 2 * math.pi / inv
+    scaled = torch.where(wavelen > old / lo, inv / factor, inv)
+    smooth = (old / wavelen - lo) / (hi - lo)
+    smoothed = (1 - smooth) * scaled / factor + smooth * scaled
+    medium = ~(wavelen < old / hi) & ~(wavelen > old / lo)
+    return torch.where(medium, smoothed, scaled)
+
+
+def llama_rms_norm(x, w, eps):
+    return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def llama_layer(sd, x, cos, sin, allow, H, Hkv, eps):
+    """one LlamaDecoderLayer: x + o(attn(rope(q), rope(k), v)) ; x + down(silu(gate) * up).  allow: [B,1,L,L] bool"""
+    B, L, D = x.shape
+    hd = D // H
+    h = llama_rms_norm(x, sd["input_layernorm.weight"], eps)
+    q = (h @ sd["self_attn.q_proj.weight"].T).view(B, L, H, hd).transpose(1, 2)
+    k = (h @ sd["self_attn.k_proj.weight"].T).view(B, L, Hkv, hd).transpose(1, 2)
+    v = (h @ sd["self_attn.v_proj.weight"].T).view(B, L, Hkv, hd).transpose(1, 2)
+
+    def rope(t):
+        return t * cos + torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1) * sin
+    q, k = rope(q), rope(k)
+    k = k.repeat_interleave(H // Hkv, 1)
+    v = v.repeat_interleave(H // Hkv, 1)
+    dots = (q @ k.transpose(-1, -2)) * hd ** -0.5
+    dots = dots.masked_fill(~allow, torch.finfo(dots.dtype).min)
+    a = (dots.softmax(-1) @ v).transpose(1, 2).reshape(B, L, D)
+    x = x + a @ sd["self_attn.o_proj.weight"].T
+    h = llama_rms_norm(x, sd["post_attention_layernorm.weight"], eps)
+    m = F.silu(h @ sd["mlp.gate_proj.weight"].T) * (h @ sd["mlp.up_proj.weight"].T)
+    return x + m @ sd["mlp.down_proj.weight"].T
+
+
+def llama_model(sd, cfg, inputs_embeds, attention_mask):
+    """LlamaModel.forward(inputs_embeds=, attention_mask=) -> last hidden state (positions = arange(L))"""
+    B, L, D = inputs_embeds.shape
+    H, Hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    inv = llama_inv_freq(D // H, cfg["rope_theta"], cfg.get("rope_scaling"))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos()[None, None], emb.sin()[None, None]
+    allow = torch.ones(L, L, dtype=torch.bool).tril()[None, None] & (attention_mask > 0)[:, None, None, :]
+    x = inputs_embeds
+    for i in range(cfg["num_hidden_layers"]):
+        x = llama_layer(_sub(sd, f"layers.{i}."), x, cos, sin, allow, H, Hkv, cfg["rms_norm_eps"])
+    return llama_rms_norm(x, sd["norm.weight"], cfg["rms_norm_eps"])
+
+
+def llasa_forward(sd, cfg, batch, eps, std=0.5):
+    """Llasa.forward (model_sigmaVAE.py:53-104) with the sampling noise passed in. Returns the reference's dict."""
+    m = _sub(sd, "base_model.model.")
+    text = m["embed_tokens.weight"][batch["input_ids"]]
+    lat = batch["audio_latents"] + std * eps                                        # sample(), dist_type 'fix'
+    audio = lat @ sd["audio_linear.weight"].T + sd["audio_linear.bias"]
+    x = audio * batch["audio_mask"].unsqueeze(-1) + text * batch["ids_mask"].unsqueeze(-1)
+    hidden = llama_model(m, cfg["llama"], x, batch["ids_mask"] + batch["audio_mask"])
+    h = hidden @ sd["distribution_linear.0.weight"].T + sd["distribution_linear.0.bias"]
+    pred = F.gelu(h) @ sd["distribution_linear.2.weight"].T + sd["distribution_linear.2.bias"]
+    kl = ((pred - batch["audio_distribution_l"]) ** 2 / (2 * std * std)).sum(2) / lat.shape[-1]
+    tm, em = batch["target_mask"], batch["end_mask"]
+    return {"audio_loss": (kl * tm).sum() / tm.sum(), "end_loss": (kl * em).sum() / em.sum(), "pre_mean": pred,
+            "ground_truth_audio_latents": lat}

@@ -75,3 +75,34 @@ MELVAE_CONFIGS = {
                       resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 3], [1, 3]],
                       activation="snake", snake_logscale=True, causal=False, flow_hidden_channels=16),
 }
+
+
+# Llasa fixture: a tiny Llama-3-style decoder (head_dim 64, GQA, llama3 rope scaling that is active at these lengths)
+LLASA_CONFIG = dict(
+    latent_dim=16, tokenizer_len=310,
+    llama=dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+               num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=256,
+               rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                 original_max_position_embeddings=32),
+               tie_word_embeddings=True, attention_bias=False, mlp_bias=False, hidden_act="silu"))
+
+
+def llasa_batch(lc, seed, B=3, L=40):
+    """collate()-shaped batch (twj_dataset_offline.py:371-384): text tokens, then audio frames, then right padding"""
+    rng = np.random.Generator(np.random.PCG64(_seed_for("llasa_batch", seed)))
+    lat = lc["latent_dim"]
+    ids = rng.integers(0, lc["tokenizer_len"], size=(B, L)).astype(np.int64)
+    ids_mask = np.zeros((B, L), np.float32)
+    audio_mask = np.zeros((B, L), np.float32)
+    target_mask = np.zeros((B, L), np.float32)
+    end_mask = np.zeros((B, L), np.float32)
+    for b in range(B):
+        nt = int(rng.integers(4, 10))
+        na = int(rng.integers(8, L - nt - 1)) if b else L - nt      # sample 0 fills the whole length (no padding)
+        ids_mask[b, :nt] = 1
+        audio_mask[b, nt:nt + na] = 1
+        target_mask[b, nt - 1:nt + na - 1] = 1                        # positions that predict an audio frame
+        end_mask[b, nt + na - 1] = 1                                  # position that predicts the end distribution
+    return dict(input_ids=ids, audio_latents=make_input("llasa_lat", (B, L, lat), seed),
+                audio_distribution_l=make_input("llasa_lbl", (B, L, lat), seed), ids_mask=ids_mask,
+                audio_mask=audio_mask, target_mask=target_mask, end_mask=end_mask)

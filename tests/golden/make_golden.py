@@ -318,6 +318,43 @@ def main():
         assert torch.equal(rec, rec_sampled)
         save(f"melvae_{tag}", enc=enc, rec=rec, z_p=z_p, logs_q=logs_q, rec_mean=rec_mean, rs_out=rs_out)
 
+    # ---- Llasa task model (model_sigmaVAE.py) over a tiny locally-built Llama (third-party transformers arithmetic) -------
+    import tempfile
+    for stub in ("torchaudio", "torchaudio.transforms"):   # the empty stubs above confuse transformers' availability probes
+        sys.modules.pop(stub, None)
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import model_sigmaVAE as rl
+    lc = gu.LLASA_CONFIG
+    tmp = tempfile.mkdtemp(prefix="kalle_llama_")
+    hf_cfg = LlamaConfig(**lc["llama"])
+    LlamaForCausalLM(hf_cfg).save_pretrained(tmp)
+
+    class _Tok:
+        def __len__(self):
+            return lc["tokenizer_len"]
+
+    llasa = rl.Llasa({"llm_model_name_or_path": tmp, "latent_dim": lc["latent_dim"], "audio_proj_dim": lc["llama"]["hidden_size"]},
+                     _Tok(), use_flash_attention=False)
+    load_seeded(llasa, 40)
+    llasa_inv = {k: list(v.shape) for k, v in llasa.state_dict().items()}
+    batch = gu.llasa_batch(lc, 40)
+    tb = {k: T(v) for k, v in batch.items()}
+    eps = T(gu.make_input("llasa_eps", batch["audio_latents"].shape, 40))
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps
+    try:
+        out = llasa(tb["input_ids"], tb["audio_latents"], tb["audio_distribution_l"], tb["ids_mask"], tb["audio_mask"],
+                    tb["target_mask"], tb["end_mask"])
+    finally:
+        torch.randn_like = orig
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    g = grads(llasa)
+    save("llasa", audio_loss=out["audio_loss"], end_loss=out["end_loss"], pre_mean=out["pre_mean"],
+         sampled=out["ground_truth_audio_latents"],
+         **pack_grads("", g), **{f"grad/{k}": g[k] for k in ("audio_linear.weight", "distribution_linear.2.bias",
+                                                               "base_model.model.layers.1.self_attn.k_proj.weight",
+                                                               "base_model.model.norm.weight")})
+
     # ---- state-dict key/shape inventories (the drop-in contract) ---------------------------------
     import json
     inv = {}
@@ -331,6 +368,7 @@ def main():
     inv["oobleck_autoencoder"] = {k: list(v.shape) for k, v in create_model_from_config(cfg).state_dict().items()}
     for tag, v in melvae_inv.items():
         inv[f"melvae_{tag}"] = v
+    inv["llasa"] = llasa_inv
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(inv, f, indent=0, sort_keys=True)
     print("done")

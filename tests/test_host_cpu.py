@@ -146,3 +146,50 @@ def test_melvae_state_dict_matches_reference(tag):
         m.extract_latents(torch.zeros(1, 1, 64))      # CPU tensors are refused, not emulated
     m.remove_weight_norm()
     assert "conv_pre.weight" in m.state_dict() and "conv_pre.weight_g" not in m.state_dict()
+
+
+def _tiny_llama_dir(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import golden_util as gu
+    d = tmp_path / "llama"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(gu.LLASA_CONFIG["llama"], model_type="llama")))
+    return str(d), gu
+
+
+class _Tok:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def test_llasa_state_dict_matches_reference(tmp_path):
+    """model_sigmaVAE.Llasa drop-in: HF key names / shapes incl. the tied lm_head, fused q/k/v and up/gate parameters split
+    and merged by the state-dict hooks, resize_token_embeddings, CPU tensors refused"""
+    path, gu = _tiny_llama_dir(tmp_path)
+    from kalle_audio_amd.model_sigmaVAE import Llasa
+    lc = gu.LLASA_CONFIG
+    m = Llasa({"llm_model_name_or_path": path, "latent_dim": lc["latent_dim"], "audio_proj_dim": 128},
+              _Tok(lc["tokenizer_len"]), use_flash_attention=False)
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == _inventory()["llasa"]
+    assert sd["base_model.lm_head.weight"].data_ptr() == sd["base_model.model.embed_tokens.weight"].data_ptr()
+    new = {k: torch.randn_like(v) for k, v in sd.items()}
+    new["base_model.lm_head.weight"] = new["base_model.model.embed_tokens.weight"]
+    m.load_state_dict(new)
+    att = m.base_model.model.layers[1].self_attn
+    want = torch.cat([new[f"base_model.model.layers.1.self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+    assert torch.equal(att.qkv_proj.weight.data, want)
+    mlp = m.base_model.model.layers[0].mlp
+    want = torch.cat([new["base_model.model.layers.0.mlp.up_proj.weight"],
+                      new["base_model.model.layers.0.mlp.gate_proj.weight"]], 0)
+    assert torch.equal(mlp.up_gate_proj.weight.data, want)
+    back = m.state_dict()
+    assert all(torch.equal(back[k], new[k]) for k in new)
+    assert m.vocab_size == lc["tokenizer_len"] and m.hidden_size == 128
+    b = {k: torch.from_numpy(v) for k, v in gu.llasa_batch(lc, 40).items()}
+    with pytest.raises(RuntimeError):
+        m(b["input_ids"], b["audio_latents"], b["audio_distribution_l"], b["ids_mask"], b["audio_mask"],
+          b["target_mask"], b["end_mask"])

@@ -500,3 +500,51 @@ def test_conv_post_activation_and_fallback_kernels(ops, dev, force_v1, monkeypat
         ref = snake(F.conv_transpose1d(x, wt, bias, stride=4, padding=2))
         got = conv_ops.conv_transpose1d(x, wtp, bias, Cout=Cout, K=8, stride=4, padding=2, post_act=(1, a, b, True, 0.0))
         assert rel_l2(got, ref) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,use_mask", [(77, False), (128, True), (300, True), (513, False)])
+def test_causal_gqa_full_rotary_attention(ops, dev, N, use_mask):
+    """the Llama decoder's attention: causal, GQA (H=4 over Hkv=2), rotary over all 64 dims, key-padding mask; q/k/v read in
+    place from one fused projection output [B, N, (H + 2 Hkv) * 64]"""
+    B, H, Hkv = 2, 4, 2
+    Dq, Dk = H * 64, Hkv * 64
+    ld = Dq + 2 * Dk
+    qkv = (_mk((B, N, ld), dev, seed=90) * 0.8).bfloat16()
+    dout = _mk((B, N, Dq), dev, seed=91).bfloat16()
+    pos = torch.arange(N, device=dev, dtype=torch.float32)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, 64, 2, device=dev, dtype=torch.float32) / 64))
+    fr = pos[:, None] * inv[None, :]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()          # [N, 32]
+    mask = None
+    if use_mask:
+        mask = torch.ones(B, N, dtype=torch.bool, device=dev)
+        mask[0, N - N // 5:] = False                                  # right padding on one sample
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr[..., :Dq], qr[..., Dq:Dq + Dk], qr[..., Dq + Dk:]
+
+    def rope(t):   # [B, h, N, 64], HF apply_rotary_pos_emb
+        c = torch.cat([cos, cos], -1)[None, None]
+        s = torch.cat([sin, sin], -1)[None, None]
+        return t * c + torch.cat([-t[..., 32:], t[..., :32]], -1) * s
+    qh = rope(q.reshape(B, N, H, 64).transpose(1, 2))
+    kh = rope(k.reshape(B, N, Hkv, 64).transpose(1, 2)).repeat_interleave(H // Hkv, 1)
+    vh = v.reshape(B, N, Hkv, 64).transpose(1, 2).repeat_interleave(H // Hkv, 1)
+    dots = qh @ kh.transpose(-1, -2) / 8.0
+    allow = torch.ones(N, N, dtype=torch.bool, device=dev).tril()[None, None]
+    if mask is not None:
+        allow = allow & mask[:, None, None, :]
+    dots = dots.masked_fill(~allow, -torch.finfo(dots.dtype).max)
+    ref = (dots.softmax(-1) @ vh).transpose(1, 2).reshape(B, N, Dq)
+    valid = mask if mask is not None else torch.ones(B, N, dtype=torch.bool, device=dev)
+    ref.backward(dout.float() * valid[..., None])                     # padded query rows carry no gradient
+    kw = dict(ldq=ld, q_off=0, ldk=ld, k_off=Dq, ldv=ld, v_off=Dq + Dk, B=B, H=H, Hkv=Hkv, Nq=N, Nk=N,
+              rope=(cos, sin), key_mask=mask, causal=True)
+    out, lse = ops.attention_fwd(qkv, qkv, qkv, **kw)
+    assert rel_l2(out[valid], ref[valid]) < 1e-2, rel_l2(out[valid], ref[valid])
+    dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(qkv, qkv, qkv, out, (dout * valid[..., None]).contiguous(), lse, dqkv, dqkv, dqkv, **kw)
+    g = qr.grad
+    for name, sl in (("dq", slice(0, Dq)), ("dk", slice(Dq, Dq + Dk)), ("dv", slice(Dq + Dk, ld))):
+        e = rel_l2(dqkv[..., sl], g[..., sl])
+        assert e < 2e-2, (name, e)

@@ -343,3 +343,108 @@ def test_melvae_ragged_lengths_against_oracle(dev):
     with torch.no_grad():
         got = vae.extract_latents(wav.to(dev))
     assert rel(got, want) < 1e-4, rel(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ Llasa (a26)
+class _Tok:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def _llasa(dev, tmp_path, seed=40):
+    import json
+    from kalle_audio_amd.model_sigmaVAE import Llasa
+    lc = gu.LLASA_CONFIG
+    d = tmp_path / "llama"
+    d.mkdir(exist_ok=True)
+    (d / "config.json").write_text(json.dumps(dict(lc["llama"], model_type="llama")))
+    m = Llasa({"llm_model_name_or_path": str(d), "latent_dim": lc["latent_dim"], "audio_proj_dim": 128},
+              _Tok(lc["tokenizer_len"]), use_flash_attention=False)
+    inv = json.load(open(os.path.join(G, "state_dict_keys.json")))["llasa"]
+    shapes = [(k, tuple(v)) for k, v in inv.items() if k != "base_model.lm_head.weight"]
+    sd = {k: torch.from_numpy(v) for k, v in gu.make_state(shapes, seed).items()}
+    sd["base_model.lm_head.weight"] = sd["base_model.model.embed_tokens.weight"]
+    m.load_state_dict(sd)
+    return m.to(dev), lc, sd
+
+
+def _hf_grads(m):
+    """parameter gradients under the reference's (HF) names: the fused q/k/v and up/gate gradients split like the weights"""
+    g = {}
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        if n.endswith("qkv_proj.weight") or n.endswith("up_gate_proj.weight"):
+            mod = m.get_submodule(n.rsplit(".", 1)[0])
+            o = 0
+            for name, k in mod.parts:
+                g[n.rsplit(".", 2)[0] + "." + name + ".weight"] = p.grad[o:o + k]
+                o += k
+        else:
+            g[n] = p.grad
+    return g
+
+
+@pytest.mark.gpu
+def test_llasa_forward_backward_vs_reference_fixture(dev, tmp_path):
+    """model_sigmaVAE.Llasa on the HIP path (bf16 GEMM operands) against the reference run (fp32): losses, prediction,
+    sampled latents, and every parameter gradient (digests: norm within 2 %, full tensors for four of them)"""
+    m, lc, _ = _llasa(dev, tmp_path)
+    f = fx("llasa")
+    b = {k: torch.from_numpy(v).to(dev) for k, v in gu.llasa_batch(lc, 40).items()}
+    eps = T(gu.make_input("llasa_eps", tuple(b["audio_latents"].shape), 40), dev)
+    out = m(b["input_ids"], b["audio_latents"], b["audio_distribution_l"], b["ids_mask"], b["audio_mask"],
+            b["target_mask"], b["end_mask"], noise=eps)
+    assert rel(out["ground_truth_audio_latents"], f["sampled"]) < 1e-6
+    assert abs(out["audio_loss"].item() - float(f["audio_loss"])) < 1e-2 * float(f["audio_loss"])
+    assert abs(out["end_loss"].item() - float(f["end_loss"])) < 1e-2 * float(f["end_loss"])
+    valid = (b["ids_mask"] + b["audio_mask"]) > 0                      # padded rows are undefined in both
+    assert rel(out["pre_mean"][valid], torch.from_numpy(f["pre_mean"]).to(dev)[valid]) < 1e-2
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    g = _hf_grads(m)
+    n = 0
+    for k in f.files:
+        if k.startswith("digest/"):
+            name = k[7:]
+            ref = f[k]
+            got = gu.digest(g[name].detach().float().cpu().numpy())
+            assert abs(got[0] - ref[0]) <= 2e-2 * ref[0] + 1e-7, (name, got[0], ref[0])
+            n += 1
+        if k.startswith("grad/"):
+            assert rel(g[k[5:]], f[k]) < 2e-2, (k, rel(g[k[5:]], f[k]))
+    assert n == 26
+
+
+@pytest.mark.gpu
+def test_llasa_through_trainer_matches_autograd(dev, tmp_path):
+    """engine.DataParallelTrainer over the Llasa model (one bucket per decoder layer, wgrads and the embedding scatter
+    straight into the flat gradient): same gradients as the plain-autograd path, and a step changes the weights"""
+    from kalle_audio_amd.engine import DataParallelTrainer
+    m, lc, _ = _llasa(dev, tmp_path)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in gu.llasa_batch(lc, 40).items()}
+    eps = T(gu.make_input("llasa_eps", tuple(b["audio_latents"].shape), 40), dev)
+    args = (b["input_ids"], b["audio_latents"], b["audio_distribution_l"], b["ids_mask"], b["audio_mask"],
+            b["target_mask"], b["end_mask"])
+    out = m(*args, noise=eps)
+    (out["audio_loss"] + 0.5 * out["end_loss"]).backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    tr = DataParallelTrainer(m, lr=1e-3, optimizer="AdamW", weight_decay=0.0)
+    assert len(tr.blocks) == 2 and "_rest" in tr.flat.bucket_range
+    before = tr.flat.param.clone()
+    out = m(*args, noise=eps)
+    loss = out["audio_loss"] + 0.5 * out["end_loss"]
+    lr0, tr.lr = tr.lr, 0.0                                             # first: gradients only
+    tr.backward(loss)
+    for n, p in m.named_parameters():
+        assert rel(tr.flat.grad_view(n), want[n]) < 1e-5, n
+    assert torch.equal(tr.flat.param, before)
+    tr.lr = lr0
+    out = m(*args, noise=eps)
+    tr.backward(out["audio_loss"] + 0.5 * out["end_loss"])
+    assert (tr.flat.param - before).abs().max() > 1e-4
+    out2 = m(*args, noise=eps)
+    assert out2["audio_loss"].item() < out["audio_loss"].item()       # one Adam step on the same batch lowers the loss

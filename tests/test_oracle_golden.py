@@ -232,3 +232,22 @@ def test_activation1d_properties():
     assert (y - x)[..., 20:-20].abs().max() < 2e-3
     const = torch.full((1, 2, 50), 0.7)
     assert torch.allclose(ko.upsample1d_2x(const, filt), torch.full((1, 2, 100), 0.7), atol=1e-6)
+
+
+def test_llasa():
+    """model_sigmaVAE.Llasa over a tiny Llama: losses, prediction, sampled latents and every parameter gradient"""
+    import json
+    f = fx("llasa")
+    lc = gu.LLASA_CONFIG
+    inv = json.load(open(os.path.join(G, "state_dict_keys.json")))["llasa"]
+    shapes = [(k, tuple(v)) for k, v in inv.items() if k != "base_model.lm_head.weight"]
+    sd = state(shapes, 40)
+    batch = {k: T(v) for k, v in gu.llasa_batch(lc, 40).items()}
+    eps = T(gu.make_input("llasa_eps", tuple(batch["audio_latents"].shape), 40))
+    out = ko.llasa_forward(sd, lc, batch, eps)
+    close(out["audio_loss"], f["audio_loss"], 1e-5)
+    close(out["end_loss"], f["end_loss"], 1e-5)
+    close(out["pre_mean"], f["pre_mean"], 1e-5)
+    close(out["ground_truth_audio_latents"], f["sampled"])
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    check_digests(f, sd, tol=5e-5)
