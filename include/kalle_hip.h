@@ -188,7 +188,9 @@ int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w
  * rope_cos/rope_sin: [Npos][rot/2] fp32 tables or NULL - rotary on the first `rot` dims of q and k, applied on the fly:
  *   rot = 32 the DiT's partial rotary (transformer.py:146-170, 430-444), rot = 64 the Llama decoder's (HF
  *   `apply_rotary_pos_emb`, the third-party model under model_sigmaVAE.py:17-29).
- * causal != 0: query i attends keys j <= i + (Nk - Nq) only (the Llama decoder called at model_sigmaVAE.py:78-81).
+ * causal != 0: query i attends keys j <= i + (Nk - Nq) only (the Llama decoder called at model_sigmaVAE.py:78-81); the
+ *   queries are then the LAST Nq positions (rotary position of query row i = i + Nk - Nq), which is what decoding against
+ *   a KV cache needs (model_sigmaVAE.py:122-146 re-runs the prefix instead).
  * key_mask: uint8 [B][Nk] (1 = attend) or NULL.  lse: [B][H][Nq] fp32 saved for backward.  head dim fixed at 64.
  */
 int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,

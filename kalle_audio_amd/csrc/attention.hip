@@ -29,7 +29,7 @@ constexpr float NEG_BIG = -1.0e30f;
 template <int NT>
 __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
-                                           int tid) {
+                                           int tid, int pos_off = 0) {
 #pragma unroll
     for (int i = 0; i < 1024 / NT; ++i) {
         const int id = tid + NT * i;
@@ -41,8 +41,8 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t
             const int hc = rot >> 4;                    // 8-element chunks per rotary half (2 or 4)
             if (rot && c < 2 * hc) {
                 const i32x4 pv = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ hc));
-                const float* cp = cosT + (int64_t)(row0 + row) * (rot >> 1) + (c & (hc - 1)) * 8;
-                const float* sp = sinT + (int64_t)(row0 + row) * (rot >> 1) + (c & (hc - 1)) * 8;
+                const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
+                const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 const float sg = (c < hc) ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
@@ -108,6 +108,7 @@ struct AttnParams {
     const uint8_t* mask;
     int B, H, Hkv, Nq, Nk;
     int causal;          // keys j <= i + (Nk - Nq) only
+    int qpos;            // rotary position of query row 0 (Nk - Nq when causal: queries are the LAST Nq positions, KV cache)
     // backward only
     const bf16_t* dout; const float* delta;
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     const bf16_t* ksrc = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
     const bf16_t* vsrc = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
 
-    stage_tile<NT>(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid);
+    stage_tile<NT>(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos);
     __syncthreads();
     bf16x8 qf[QT][2];
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
         const int val = min(128, p.Nq - o0);
         const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hown * 64;
         const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hown * 64;
-        stage_tile<NT>(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid);
+        stage_tile<NT>(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid, p.qpos);
         stage_tile<NT>(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
     }
     __syncthreads();
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
             if constexpr (KV) {
                 const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hq * 64;
                 const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hq * 64;
-                stage_tile<NT>(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                stage_tile<NT>(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid, p.qpos);
                 stage_tile<NT>(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
                 if (tid < 128) {
                     const bool ok = tid < sval;
@@ -468,8 +469,9 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
 #pragma unroll
             for (int ht = 0; ht < 2; ++ht) {
                 if (ht >= hts) break;
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
+                const int64_t pos = oi + (KV ? 0 : p.qpos);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + pos * (p.rot >> 1) + 16 * ht + 4 * g);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + pos * (p.rot >> 1) + 16 * ht + 4 * g);
                 f32x4& lo = hts == 1 ? g2[0][ot] : g2[ht][ot];
                 f32x4& hi = hts == 1 ? g2[1][ot] : g2[ht + 2][ot];
 #pragma unroll
@@ -533,6 +535,7 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
     if (causal && Nk < Nq) return KALLE_ERR_ARG;
+    p.qpos = causal ? Nk - Nq : 0;
     constexpr int lds = 3 * AT_TILE + 128 * 4;
     static bool attr = false;
     if (!attr) {
@@ -562,6 +565,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
     if (causal && Nk < Nq) return KALLE_ERR_ARG;
+    p.qpos = causal ? Nk - Nq : 0;
     p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 

@@ -108,3 +108,23 @@ def layer_bwd(p, saved, g, B, L, rope, mask8, go=None, g_bf16=None, want_dx_bf16
     dxb = torch.empty((M, D), device=g.device, dtype=BF16) if want_dx_bf16 else None
     dx = go.rms("input_layernorm.weight", dh1, x, p.g1, rr1, dres=dx2, dx_bf16=dxb)
     return dx, dxb, go
+
+
+def layer_fwd_cached(p, x, kv_cache, t0, rope):
+    """inference with a KV cache (batch 1): x fp32 [n, D] are positions t0 .. t0+n-1; kv_cache bf16 [Lmax, 2*Hkv*64]
+    holds the un-rotated k | v rows of positions < t0 and receives the new ones (rotary is applied by the attention
+    kernel from the row index, so cached keys need no re-rotation).  Returns fp32 [n, D]."""
+    H, Hkv = p.H, p.Hkv
+    D = H * 64
+    ld = (H + 2 * Hkv) * 64
+    n = x.shape[0]
+    h1, _ = ops.rmsnorm_fwd(x, p.g1, eps=p.eps, out_dtype=BF16)
+    qkv = ops.gemm(h1, p.wqkv)
+    ops.copy_rows(qkv[:, D:], kv_cache[t0:], 1, n, 2 * Hkv * 64, 0, ld, 0, 2 * Hkv * 64)
+    ao, _ = ops.attention_fwd(qkv, kv_cache, kv_cache, ldq=ld, q_off=0, ldk=2 * Hkv * 64, k_off=0, ldv=2 * Hkv * 64,
+                              v_off=Hkv * 64, B=1, H=H, Hkv=Hkv, Nq=n, Nk=t0 + n, rope=rope, causal=True)
+    x2 = ops.gemm(ao.view(n, D), p.wo, out_dtype=F32, residual=x)
+    h2, _ = ops.rmsnorm_fwd(x2, p.g2, eps=p.eps, out_dtype=BF16)
+    hf = ops.gemm(h2, p.wug)
+    act = ops.swiglu_fwd(hf)
+    return ops.gemm(act, p.wdown, out_dtype=F32, residual=x2)

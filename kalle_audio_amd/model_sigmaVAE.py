@@ -273,6 +273,28 @@ class LlamaModel(nn.Module):
         return (self.norm(x),)
 
 
+    # ---- inference with a KV cache (batch 1) ---------------------------------------------------------------------
+    def init_cache(self, max_len, device):
+        """one bf16 [max_len, 2 * kv_heads * 64] buffer per layer (un-rotated k | v rows)"""
+        w = 2 * self.cfg["num_key_value_heads"] * 64
+        return {"kv": [torch.zeros((max_len, w), device=device, dtype=BF16) for _ in self.layers], "len": 0,
+                "rope": LO.rope_tables(max_len, self._inv_freq, device)}
+
+    @torch.no_grad()
+    def forward_cached(self, inputs_embeds, cache):
+        """appends the positions of `inputs_embeds` [1, n, D] to the cache and returns their last hidden states"""
+        _need_gpu(inputs_embeds)
+        _, n, Dm = inputs_embeds.shape
+        t0 = cache["len"]
+        if t0 + n > cache["kv"][0].shape[0]:
+            raise ValueError("KV cache too short")
+        x = Fn._to_f32(inputs_embeds.contiguous()).view(n, Dm)
+        for layer, kv in zip(self.layers, cache["kv"]):
+            x = LO.layer_fwd_cached(LO.layer_params(layer), x, kv, t0, cache["rope"])
+        cache["len"] = t0 + n
+        return self.norm(x.view(1, n, Dm))
+
+
 class LlamaForCausalLM(nn.Module):
     """the parts of transformers' LlamaForCausalLM the task model touches: `.model`, `.config`, `.vocab_size`,
     `resize_token_embeddings`, tied `lm_head.weight` in the state dict"""
@@ -385,10 +407,11 @@ class Llasa(nn.Module):
 
     @torch.no_grad()
     def infer(self, input_ids, audio_latents, end_disp_kl_thres=0.5, max_length=200, sample=False, use_cfg=None,
-              flow=None):
-        """model_sigmaVAE.py:106-148: frame-by-frame generation; each step re-runs the decoder over the whole prefix
-        (as the reference does) and stops when KL(N(mean, std) || N(1, e)) / dim < threshold"""
-        dev = input_ids.device
+              flow=None, use_cache=True):
+        """model_sigmaVAE.py:106-148: frame-by-frame generation, stopping when KL(N(mean, std) || N(1, e)) / dim drops
+        below the threshold.  The reference re-runs the decoder over the whole prefix for every frame (O(T^2) GEMM work);
+        with use_cache (default) the prompt is prefilled once and every frame is one single-position pass against a KV
+        cache - same arithmetic per position.  use_cache=False reproduces the reference's schedule."""
         ids = input_ids.unsqueeze(0)
         text_embed = self.base_model.model.embed_tokens(ids)
         parts = [text_embed]
@@ -396,8 +419,14 @@ class Llasa(nn.Module):
             parts.append(self.audio_linear(audio_latents))
         input_embed = torch.cat(parts, dim=1)
         final = []
+        model = self.base_model.model
+        cache = model.init_cache(input_embed.shape[1] + max_length, input_embed.device) if use_cache else None
+        step_in = input_embed
         for i in range(max_length):
-            hidden = self.base_model.model(inputs_embeds=input_embed)[0]
+            if use_cache:
+                hidden = model.forward_cached(step_in, cache)
+            else:
+                hidden = model(inputs_embeds=input_embed)[0]
             mean2 = self.distribution_linear(hidden[:, -1:, :].contiguous())
             audio_latent = self.sample(mean2)
             final.append(audio_latent)
@@ -407,7 +436,9 @@ class Llasa(nn.Module):
             kl = kl / mean2.shape[2]
             if kl.item() < end_disp_kl_thres and i > 3:
                 break
-            input_embed = torch.cat((input_embed, self.audio_linear(audio_latent)), dim=1)
+            step_in = self.audio_linear(audio_latent)
+            if not use_cache:
+                input_embed = torch.cat((input_embed, step_in), dim=1)
         out = torch.stack(final[:-1], dim=1).squeeze(1).squeeze(2)
         return out.transpose(1, 2)
 

@@ -448,3 +448,38 @@ def test_llasa_through_trainer_matches_autograd(dev, tmp_path):
     assert (tr.flat.param - before).abs().max() > 1e-4
     out2 = m(*args, noise=eps)
     assert out2["audio_loss"].item() < out["audio_loss"].item()       # one Adam step on the same batch lowers the loss
+
+
+@pytest.mark.gpu
+def test_llasa_kv_cache_matches_full_forward(dev, tmp_path):
+    """prefill + one-position-at-a-time decoding against the KV cache gives the hidden states of the full causal forward
+    (rotary position of a cached query = its absolute position), and infer() with / without the cache generate the same
+    frames when fed the same noise"""
+    m, lc, _ = _llasa(dev, tmp_path)
+    model = m.base_model.model
+    torch.manual_seed(3)
+    x = torch.randn(1, 37, 128, device=dev)
+    with torch.no_grad():
+        full = model(inputs_embeds=x)[0]
+        cache = model.init_cache(64, dev)
+        got = [model.forward_cached(x[:, :20].contiguous(), cache)]
+        for t in range(20, 37):
+            got.append(model.forward_cached(x[:, t:t + 1].contiguous(), cache))
+        got = torch.cat(got, 1)
+    assert cache["len"] == 37
+    assert rel(got, full) < 1e-2, rel(got, full)
+    ids = torch.randint(0, 300, (9,), device=dev)
+    prompt = torch.randn(1, 5, lc["latent_dim"], device=dev)
+    noise = torch.randn(12, 1, 1, lc["latent_dim"], device=dev)
+    outs = []
+    for use_cache in (True, False):
+        it = iter(noise)
+        m.sample = lambda mean, dist_type='fix', noise=None, it=it: ops_axpby(mean, next(it))
+        outs.append(m.infer(ids, prompt, end_disp_kl_thres=-1.0, max_length=8, use_cache=use_cache))
+    assert outs[0].shape == outs[1].shape == (1, lc["latent_dim"], 7)
+    assert rel(outs[0], outs[1]) < 2e-2, rel(outs[0], outs[1])
+
+
+def ops_axpby(mean, n):
+    from kalle_audio_amd import ops
+    return ops.axpby(mean.float().contiguous(), n.reshape(mean.shape).float().contiguous(), 1.0, 0.5)

@@ -56,3 +56,17 @@ fl = (6.0 * nonemb + 16 * 12.0 * L * 2048 * 0.5) * B * L
 print(f"Llasa Llama-3.2-1B-shape train step B={B} L={L}: {dt*1e3:.1f} ms/step, {B*L/dt:.0f} tokens/s, "
       f"{B*L/12.5/dt:.0f} audio-s/s (12.5 Hz frames), {fl/dt/1e12:.0f} TFLOP/s algorithmic, params {nparam/1e9:.2f} B, "
       f"loss {out['audio_loss'].item():.3f}")
+
+if "--infer" in sys.argv:
+    # frame-by-frame generation (Llasa.infer): 64 prompt tokens, 200 frames, KV cache vs the reference's full re-forward
+    m.eval()
+    pid = torch.randint(0, 128264, (64,), device=dev)
+    for use_cache, nfr in ((True, 200), (False, 200)):
+        m.infer(pid, None, end_disp_kl_thres=-1.0, max_length=4, use_cache=use_cache)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = m.infer(pid, None, end_disp_kl_thres=-1.0, max_length=nfr, use_cache=use_cache)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"infer use_cache={use_cache}: {nfr} frames in {dt*1e3:.0f} ms = {nfr/dt:.1f} frames/s "
+              f"({nfr/dt/12.5:.2f} x real time at 12.5 Hz), out {tuple(out.shape)}")
