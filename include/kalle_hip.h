@@ -267,6 +267,9 @@ int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed
  */
 /* out = a x + b y, fp32   (fixed-sigma sampling x = mean + std * randn, model_sigmaVAE.py:150-166) */
 int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream);
+/* waveform -> int16 PCM as the inference scripts write it (infer_0723.py:293): out = int16(clamp(x / max|x|, -1, 1) * 32767);
+ * peak: one fp32 of device scratch that receives max|x|; x fp32 or bf16 */
+int kalle_peak_normalize_int16(const void* x, int dtype, float* peak, int16_t* out, int64_t n, void* stream);
 /* out[r, :] = audio[r, :] * audio_mask[r] + table[ids[r], :] * ids_mask[r]   (embed_tokens + masked mix, :66-73);
  * table fp32 [vocab][D], audio fp32 or bf16 [rows][D], masks fp32 [rows], out fp32 */
 int kalle_embed_mix_fwd(const int64_t* ids, const float* table, const void* audio, int audio_dtype, const float* ids_mask,

@@ -21,6 +21,31 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
         out[i] = a * x[i] + b * y[i];
 }
 
+// peak normalisation to int16 (infer_0723.py:293: x / max|x| -> clamp(-1, 1) * 32767 -> int16, truncating like .to(int16))
+template <bool F32>
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ x, unsigned* __restrict__ peak_bits, int64_t n) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(F32 ? static_cast<const float*>(x)[i] : bf16_to_f32(static_cast<const bf16_t*>(x)[i])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)   // non-negative floats order like their bit patterns
+        atomicMax(peak_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+template <bool F32>
+__global__ __launch_bounds__(256) void to_int16_kernel(const void* __restrict__ x, const unsigned* __restrict__ peak_bits,
+                                                       int16_t* __restrict__ out, int64_t n) {
+    const float peak = __uint_as_float(peak_bits[0]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = __fdiv_rn(F32 ? static_cast<const float*>(x)[i] : bf16_to_f32(static_cast<const bf16_t*>(x)[i]), peak);
+        v = fminf(fmaxf(v, -1.f), 1.f) * 32767.f;
+        out[i] = (int16_t)(int)v;
+    }
+}
+
 // out[r, :] = audio[r, :] * am[r] + table[ids[r], :] * im[r]     (model_sigmaVAE.py:66, 73)
 template <bool AF32>
 __global__ __launch_bounds__(256) void embed_mix_fwd_kernel(const int64_t* __restrict__ ids,
@@ -148,6 +173,21 @@ __global__ __launch_bounds__(256) void gauss_kl_bwd_kernel(const float* __restri
 extern "C" int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream) {
     if (!x || !y || !out || n <= 0) return KALLE_ERR_ARG;
     KALLE_LAUNCH(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, out, a, b, n);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_peak_normalize_int16(const void* x, int dtype, float* peak, int16_t* out, int64_t n, void* stream) {
+    if (!x || !peak || !out || n <= 0) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(peak, 0, sizeof(float), st) != hipSuccess) return KALLE_ERR_LAUNCH;
+    unsigned* pb = reinterpret_cast<unsigned*>(peak);
+    if (dtype == KALLE_F32) {
+        KALLE_LAUNCH((absmax_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, pb, n);
+        KALLE_LAUNCH((to_int16_kernel<true>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, pb, out, n);
+    } else {
+        KALLE_LAUNCH((absmax_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, pb, n);
+        KALLE_LAUNCH((to_int16_kernel<false>), dim3(grid_for(n, 256)), dim3(256), 0, st, x, pb, out, n);
+    }
     return kalle_check_launch();
 }
 

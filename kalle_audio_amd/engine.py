@@ -74,6 +74,34 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+class EMASchedule:
+    """decay schedule of `ema_pytorch.EMA` as the reference configures it (training/diffusion.py:240-248: beta=0.9999,
+    power=3/4, update_every=1, update_after_step=1; third-party, unpinned - restated from the package's published
+    algorithm, parity unpinned): until `update_after_step` the average is a copy of the weights, then
+    ema += (1 - decay) (w - ema) with decay = clamp(1 - (1 + epoch / inv_gamma)^-power, min_value, beta)."""
+
+    def __init__(self, beta=0.9999, power=2 / 3, update_every=10, update_after_step=100, inv_gamma=1.0, min_value=0.0):
+        self.beta, self.power, self.update_every = beta, power, update_every
+        self.update_after_step, self.inv_gamma, self.min_value = update_after_step, inv_gamma, min_value
+        self.step = 0
+        self.initted = False
+
+    def next(self):
+        """advance one optimizer step; returns None (skip), "copy", or the decay to use"""
+        step = self.step
+        self.step += 1
+        if step % self.update_every != 0:
+            return None
+        if step <= self.update_after_step or not self.initted:
+            self.initted = step > self.update_after_step or self.initted
+            return "copy"
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        return min(max(value, self.min_value), self.beta)
+
+
 class FlatBuckets:
     """Flat fp32 parameter / gradient storage partitioned into all-reduce buckets.  Device-agnostic (the gloo CPU
     tests exercise exactly this class); only the optimizer launch needs the GPU."""
@@ -213,6 +241,25 @@ class DataParallelTrainer:
             self.optimizer_step()
         self.micro += 1
 
+    # -- exponential moving average of the weights (reference: ema_pytorch.EMA, training/diffusion.py:240-248, 440-441) --
+    def enable_ema(self, **kw):
+        self.ema_schedule = EMASchedule(**kw)
+        self.ema = self.flat.param.clone()
+        return self
+
+    def _ema_update(self):
+        d = self.ema_schedule.next()
+        if d is None:
+            return
+        if d == "copy":
+            self.ema.copy_(self.flat.param)
+        else:
+            ops.axpby(self.ema, self.flat.param, d, 1.0 - d, out=self.ema)   # one fused pass over the flat buffers
+
+    def ema_state_dict(self):
+        """the averaged weights under the model's parameter names (views into the flat EMA buffer)"""
+        return {n: self.ema[s:s + ne].view(self.flat.params[n].shape) for n, (s, ne) in self.flat.slices.items()}
+
     def optimizer_step(self):
         self.step_count += 1
         lr = self.lr * (self.lr_schedule(self.step_count) if self.lr_schedule else 1.0)
@@ -220,6 +267,8 @@ class DataParallelTrainer:
         ops.adam_step(f.param, f.grad, self.exp_avg, self.exp_avg_sq, f.param_bf16, lr=lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, decoupled=self.decoupled,
                       step=self.step_count, grad_scale=1.0 / (self.world * self.grad_accum_steps))
+        if getattr(self, "ema", None) is not None:
+            self._ema_update()
 
     def train_step(self, diffusion, latents, t, noise, cond, objective="v", padding_mask=None):
         """fwd + bwd + all-reduce + optimizer for one micro-batch. Returns the (device) loss tensor, no host sync."""

@@ -354,11 +354,23 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, ldq, q_off, ldk, k_off
 
 
 # ------------------------------------------------------------------------------------------------ Llasa head / tail
-def axpby(x, y, a, b):
+def peak_normalize_int16(x):
+    """int16(clamp(x / max|x|, -1, 1) * 32767) (infer_0723.py:293); returns (int16 tensor of x's shape, peak [1] fp32)"""
+    lib = _lib.load()
+    x = x.contiguous()
+    peak = torch.empty(1, device=x.device, dtype=torch.float32)
+    out = torch.empty(x.shape, device=x.device, dtype=torch.int16)
+    check(lib.kalle_peak_normalize_int16(_p(x), _dt(x), _p(peak), _p(out), x.numel(), _stream()),
+          "kalle_peak_normalize_int16")
+    return out, peak
+
+
+def axpby(x, y, a, b, out=None):
+    """out = a x + b y (fp32); out may alias x or y"""
     lib = _lib.load()
     x, y = x.contiguous(), y.contiguous()
     assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else out
     check(lib.kalle_axpby(_p(x), _p(y), _p(out), float(a), float(b), x.numel(), _stream()), "kalle_axpby")
     return out
 

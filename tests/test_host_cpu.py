@@ -193,3 +193,19 @@ def test_llasa_state_dict_matches_reference(tmp_path):
     with pytest.raises(RuntimeError):
         m(b["input_ids"], b["audio_latents"], b["audio_distribution_l"], b["ids_mask"], b["audio_mask"],
           b["target_mask"], b["end_mask"])
+
+
+def test_ema_schedule():
+    """decay schedule of the reference's EMA configuration (training/diffusion.py:240-248)"""
+    from kalle_audio_amd.engine import EMASchedule
+    s = EMASchedule(beta=0.9999, power=3 / 4, update_every=1, update_after_step=1)
+    acts = [s.next() for _ in range(6)]
+    assert acts[0] == "copy" and acts[1] == "copy"           # steps 0, 1 <= update_after_step: plain copies
+    assert acts[2] == "copy"                                  # first step past the warm-up initialises the average
+    assert abs(acts[3] - (1 - (1 + 2) ** -0.75)) < 1e-12      # epoch = step_count - update_after_step - 1 = 2
+    assert abs(acts[4] - (1 - (1 + 3) ** -0.75)) < 1e-12
+    big = EMASchedule(beta=0.9999, power=3 / 4, update_every=1, update_after_step=1)
+    big.step, big.initted = 10 ** 7, True
+    assert big.next() == 0.9999
+    sk = EMASchedule(update_every=10, update_after_step=0)
+    assert [sk.next() is None for _ in range(11)] == [False] + [True] * 9 + [False]

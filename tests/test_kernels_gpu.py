@@ -548,3 +548,17 @@ def test_causal_gqa_full_rotary_attention(ops, dev, N, use_mask):
     for name, sl in (("dq", slice(0, Dq)), ("dk", slice(Dq, Dq + Dk)), ("dv", slice(Dq + Dk, ld))):
         e = rel_l2(dqkv[..., sl], g[..., sl])
         assert e < 2e-2, (name, e)
+
+
+@pytest.mark.gpu
+def test_peak_normalize_int16_and_axpby_inplace(ops, dev):
+    x = torch.randn(2, 3001, device=dev) * 0.3
+    got, peak = ops.peak_normalize_int16(x)
+    want = x.div(x.abs().max()).clamp(-1, 1).mul(32767).to(torch.int16)
+    assert peak.item() == x.abs().max().item()
+    assert (got.int() - want.int()).abs().max() <= 1 and (got != want).float().mean() < 1e-3
+    assert got.abs().max().item() == 32767
+    a, b = torch.randn(1000, device=dev), torch.randn(1000, device=dev)
+    want = 0.9 * a + 0.1 * b
+    ops.axpby(a, b, 0.9, 0.1, out=a)
+    assert torch.allclose(a, want, atol=1e-6)

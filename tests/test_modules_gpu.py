@@ -448,6 +448,17 @@ def test_llasa_through_trainer_matches_autograd(dev, tmp_path):
     assert (tr.flat.param - before).abs().max() > 1e-4
     out2 = m(*args, noise=eps)
     assert out2["audio_loss"].item() < out["audio_loss"].item()       # one Adam step on the same batch lowers the loss
+    # EMA of the flat weights (reference: ema_pytorch as configured in training/diffusion.py:240-248)
+    tr.enable_ema(beta=0.9999, power=3 / 4, update_every=1, update_after_step=1)
+    snaps = []
+    for _ in range(4):
+        o = m(*args, noise=eps)
+        tr.backward(o["audio_loss"] + 0.5 * o["end_loss"])
+        snaps.append(tr.flat.param.clone())
+    d = 1 - (1 + 2) ** -0.75
+    want = snaps[2] * d + snaps[3] * (1 - d)                            # copy, copy, copy(init), first averaged step
+    assert rel(tr.ema, want) < 1e-6
+    assert tr.ema_state_dict()["audio_linear.weight"].shape == m.audio_linear.weight.shape
 
 
 @pytest.mark.gpu
