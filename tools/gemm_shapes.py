@@ -1,0 +1,24 @@
+"""time arbitrary GEMM shapes: python tools/gemm_shapes.py LAYOUT M N K [M N K ...]   (LAYOUT nt|nn|tn)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kalle_audio_amd import ops
+dev = torch.device("cuda")
+lay = sys.argv[1]
+dims = list(map(int, sys.argv[2:]))
+mk = lambda r, c: (torch.randn(r, c, device=dev) * 0.5).bfloat16()
+for i in range(0, len(dims), 3):
+    M, N, K = dims[i:i + 3]
+    if lay == "nt":
+        a, b = mk(M, K), mk(N, K); fn = lambda: ops.gemm(a, b)
+    elif lay == "nn":
+        a, b = mk(M, K), mk(K, N); fn = lambda: ops.gemm(a, b, b_kmajor=True)
+    else:
+        a, b = mk(K, M), mk(K, N); fn = lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); ts.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in ts)[5]
+    print(f"{lay} {M}x{N}x{K}: {ms*1e3:.1f} us {2.0*M*N*K/ms/1e9:.0f} TF")
