@@ -230,6 +230,10 @@ class ContinuousTransformer(nn.Module):
         # an all-true mask is the common case (dit.py:189): skip the masked kernels' extra work
         if mask is not None and bool(mask.all()):
             mask = None
+        ctx = kwargs.get("context")
+        if ctx is not None and not ctx.requires_grad and ctx.dtype == torch.float32:
+            # frozen conditioning (T5 / number embedders): one bf16 cast for all layers instead of one per layer
+            kwargs = dict(kwargs, context=KF._to_bf16(ctx.contiguous()))
         for layer in self.layers:
             x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
             if return_info:
