@@ -25,22 +25,43 @@ constexpr float SM_SCALE = 0.125f;         // 1/sqrt(64)
 constexpr float NEG_BIG = -1.0e30f;
 
 // stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying rotary on the first `rot`
-// (32: DiT partial rotary; 64: Llama) dims: out = x cos + rotate_half(x) sin, tables [pos][rot/2]
+// (32: DiT partial rotary; 64: Llama) dims: out = x cos + rotate_half(x) sin, tables [pos][rot/2].
+// Split in two so that a kernel can put the global loads of several tiles in flight together (one HBM latency instead
+// of one per tile) and do the rotary + LDS writes afterwards.
 template <int NT>
-__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
+struct TileRegs {
+    i32x4 v[1024 / NT], pv[1024 / NT];
+};
+template <int NT>
+__device__ __forceinline__ void tile_load(TileRegs<NT>& t, const bf16_t* src, int64_t ld, int row0, int nvalid, int rot,
+                                          int tid) {
+#pragma unroll
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int id = tid + NT * i;
+        const int row = id >> 3, c = id & 7;
+        t.v[i] = i32x4{0, 0, 0, 0};
+        t.pv[i] = i32x4{0, 0, 0, 0};
+        if (row < nvalid) {
+            const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
+            t.v[i] = *reinterpret_cast<const i32x4*>(rp + 8 * c);
+            const int hc = rot >> 4;                    // 8-element chunks per rotary half (2 or 4)
+            if (rot && c < 2 * hc) t.pv[i] = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ hc));
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void tile_store(char* lds, const TileRegs<NT>& t, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
                                            int tid, int pos_off = 0) {
 #pragma unroll
     for (int i = 0; i < 1024 / NT; ++i) {
         const int id = tid + NT * i;
         const int row = id >> 3, c = id & 7;
-        i32x4 v = {0, 0, 0, 0};
+        i32x4 v = t.v[i];
         if (row < nvalid) {
-            const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
-            v = *reinterpret_cast<const i32x4*>(rp + 8 * c);
-            const int hc = rot >> 4;                    // 8-element chunks per rotary half (2 or 4)
+            const int hc = rot >> 4;
             if (rot && c < 2 * hc) {
-                const i32x4 pv = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ hc));
+                const i32x4 pv = t.pv[i];
                 const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
                 const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
@@ -62,6 +83,14 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t
         }
         *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * c) = v;
     }
+}
+template <int NT>
+__device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
+                                           const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
+                                           int tid, int pos_off = 0) {
+    TileRegs<NT> t;
+    tile_load<NT>(t, src, ld, row0, nvalid, rot, tid);
+    tile_store<NT>(lds, t, row0, nvalid, cosT, sinT, rot, tid, pos_off);
 }
 
 // fragment of 16 tile rows (rbase..) x 32 d (k-step s): MFMA operand whose k index is the head dim
@@ -135,7 +164,16 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     const bf16_t* ksrc = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
     const bf16_t* vsrc = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
 
-    stage_tile<NT>(Qs, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos);
+    {   // Q and the first K / V block: all global loads in flight together, then rotary + LDS writes
+        TileRegs<NT> tq, tk, tv;
+        const int kv0 = min(128, p.Nk);
+        tile_load<NT>(tq, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.rot, tid);
+        tile_load<NT>(tk, ksrc, p.ldk, 0, kv0, p.rot, tid);
+        tile_load<NT>(tv, vsrc, p.ldv, 0, kv0, 0, tid);
+        tile_store<NT>(Qs, tq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos);
+        tile_store<NT>(Ks, tk, 0, kv0, p.cosT, p.sinT, p.rot, tid);
+        tile_store<NT>(Vs, tv, 0, kv0, nullptr, nullptr, 0, tid);
+    }
     __syncthreads();
     bf16x8 qf[QT][2];
 #pragma unroll
@@ -155,10 +193,12 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     const int coff = p.Nk - p.Nq;                      // causal: query i sees keys j <= i + coff
     const int kend = p.causal ? min(p.Nk, q0 + 128 + coff) : p.Nk;
     for (int k0 = 0; k0 < kend; k0 += 128) {
-        __syncthreads();  // previous block's K/V reads are done
         const int kval = min(128, p.Nk - k0);
-        stage_tile<NT>(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
-        stage_tile<NT>(Vs, vsrc, p.ldv, k0, kval, nullptr, nullptr, 0, tid);
+        if (k0 > 0) {         // (block 0 was staged with Q)
+            __syncthreads();  // previous block's K/V reads are done
+            stage_tile<NT>(Ks, ksrc, p.ldk, k0, kval, p.cosT, p.sinT, p.rot, tid);
+            stage_tile<NT>(Vs, vsrc, p.ldv, k0, kval, nullptr, nullptr, 0, tid);
+        }
         if (tid < 128) {
             float bias = 0.f;
             if (tid >= kval) bias = -INFINITY;                                           // padding: never attended
