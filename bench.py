@@ -35,8 +35,9 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 def flops_per_clip_fwd(cfg, T=T_FRAMES, S=S_CTX):
     """algorithmic forward FLOPs per clip: 24 x (36 N D^2 + 4 S Dc^2 + 4 N^2 D + 4 N S D) + 4 N C D"""
     D, Dc, C, L = cfg["embed_dim"], cfg["cond_token_dim"], cfg["io_channels"], cfg["depth"]
-    N = T + 1
-    per_block = 36 * N * D * D + 4 * S * Dc * Dc + 4 * N * N * D + 4 * N * S * D
+    ada = cfg.get("global_cond_type") == "adaLN"
+    N = T if ada else T + 1                     # prepend: one conditioning token joins the sequence
+    per_block = 36 * N * D * D + 4 * S * Dc * Dc + 4 * N * N * D + 4 * N * S * D + (12 * D * D if ada else 0)
     return L * per_block + 4 * N * C * D
 
 
@@ -121,7 +122,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-depth", type=int, default=None, help="time a shallower oracle and scale (debug)")
+    # sweep axes of SURVEY.md 8(d) - the defaults are the headline configuration
+    ap.add_argument("--io-channels", type=int, default=CFG["io_channels"], help="latent channels: 64 | 512 | 1024")
+    ap.add_argument("--global-cond-type", default=CFG["global_cond_type"], choices=["prepend", "adaLN"])
+    ap.add_argument("--objective", default="v", choices=["v", "rectified_flow"])
     args = ap.parse_args()
+    CFG["io_channels"], CFG["global_cond_type"] = args.io_channels, args.global_cond_type
 
     import torch.distributed as dist
     from kalle_audio_amd import engine, ops
@@ -138,7 +144,7 @@ def main():
     lat, noise, t, cond = make_batch(args.batch, device, 1234 + rank)
 
     def step():
-        return trainer.train_step(model, lat, t, noise, cond, objective="v")
+        return trainer.train_step(model, lat, t, noise, cond, objective=args.objective)
 
     def fence():
         if world > 1:
@@ -175,7 +181,8 @@ def main():
                                    "10 s @ 12.5 Hz x 1024 latents (T=125+1 prepend), S=130 x 768 cross-attn cond; "
                                    "DiT shape chosen by this build (reference defines none)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "objective": "v", "loss": loss_v},
+                       "objective": args.objective, "io_channels": CFG["io_channels"],
+                       "global_cond_type": CFG["global_cond_type"], "loss": loss_v},
             "algorithmic_tflops_per_gpu": 3 * fwd * args.batch * args.steps / dt / 1e12,
             "mfma_roofline_frac_step": 3 * fwd * args.batch * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
         }
