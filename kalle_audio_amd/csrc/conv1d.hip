@@ -601,52 +601,82 @@ __global__ __launch_bounds__(256) void snake_kernel(const void* __restrict__ x, 
 //   2x kaiser-sinc FIR upsample (12 taps, replicate padding) -> snake / snake-beta -> 2x FIR low-pass downsample.
 // One workgroup = 256 consecutive outputs of one (batch, channel) row; x segment and the activated 2x-rate
 // signal live in LDS, so HBM sees one read and one write per element.
-constexpr int A1_T = 256;
+constexpr int A1_T = 1024;   // outputs per workgroup: 4 consecutive ones per thread
 template <bool F32>
 __global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                     const float* __restrict__ filt, const float* __restrict__ alpha,
                                                     const float* __restrict__ beta, int logscale, int C, int L) {
-    __shared__ float xs[A1_T + 16];
-    __shared__ float as[2 * A1_T + 16];
-    __shared__ float f[12];
+    // xs[j] = x_pad[i0 + j] (replicate padding folded in);  as[j] = act(u[clamp(2 t0 - 5 + j)])
+    __shared__ __attribute__((aligned(16))) float xs[A1_T + 16];
+    __shared__ __attribute__((aligned(16))) float as[2 * A1_T + 16];
     const int row = blockIdx.y;                     // b * C + c
     const int c = row % C;
     const int t0 = blockIdx.x * A1_T;
     const int64_t base = (int64_t)row * L;
-    if (threadIdx.x < 12) f[threadIdx.x] = filt[threadIdx.x];
-    // up-sampled index range needed: m in [2*t0 - 5, 2*t0 + 2*A1_T + 6]; x_pad index i in [(m+4+1)/2, (m+15)/2]
-    const int m0 = 2 * t0 - 5;
-    const int i0 = (m0 + 4) / 2 - 1;                // a safe lower bound of x_pad indices used (may be negative)
+    float f[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) f[j] = filt[j];    // uniform: scalar loads
+    // u index n = 2 t0 - 5 + j uses x_pad[(n + 5) >> 1 .. + 5]; j = 0 -> x_pad index t0: take i0 = t0 - 1 as slot 0
+    const int i0 = t0 - 1;
     for (int j = threadIdx.x; j < A1_T + 16; j += 256) {
-        const int xi = min(max(i0 + j - 5, 0), L - 1);   // replicate padding: x_pad[i] = x[clamp(i - 5)]
+        const int xi = min(max(i0 + j - 5, 0), L - 1);   // x_pad[i] = x[clamp(i - 5)]
         xs[j] = ld1<F32>(x, base + xi);
     }
     __syncthreads();
     float a = alpha[c], b = beta[c];
     if (logscale) { a = __expf(a); b = __expf(b); }
     const float inv_b = 1.f / (b + 1e-9f);
-    for (int j = threadIdx.x; j < 2 * A1_T + 12; j += 256) {
-        // a_pad[m] = act(u[clamp(m - 5, 0, 2L-1)]) with m = 2*t0 + j  ->  u index n:
-        const int n = min(max(2 * t0 + j - 5, 0), 2 * L - 1);
-        // u[n] = 2 * sum_i x_pad[i] f[n + 15 - 2i],  i = ceil((n+4)/2) .. floor((n+15)/2)
-        const int ilo = (n + 5) >> 1;               // ceil((n+4)/2)
-        float u = 0.f;
+    // each thread produces 8 consecutive as[] slots (+ the 12-slot tail by the first threads) from a register window of x
+    for (int j0 = 8 * threadIdx.x; j0 < 2 * A1_T + 12; j0 += 8 * 256) {
+        // slots j0..j0+7 <-> n = 2 t0 - 5 + j0 + e; x_pad index of tap q: ((n + 5) >> 1) + q = t0 + ((j0 + e) >> 1) + q
+        float xw[12];
+        const int w0 = (j0 >> 1) + 1;               // slot of x_pad[t0 + (j0 >> 1)] in xs (i0 = t0 - 1)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int i = ilo + q;
-            const int tap = n + 15 - 2 * i;
-            if (tap >= 0 && tap < 12) u += xs[i - i0] * f[tap];
+        for (int q = 0; q < 10; ++q) xw[q] = xs[min(w0 + q, A1_T + 15)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = j0 + e;
+            if (j >= 2 * A1_T + 12) break;
+            const int n = 2 * t0 - 5 + j;
+            // tap of x_pad[t0 + (j >> 1) + q] is n + 15 - 2 i = 10 + (j & 1) - 2 q: even slots use taps 10, 8, .., 0 and odd
+            // slots 11, 9, .., 1 (e and j have the same parity: j0 is a multiple of 8)
+            float u = 0.f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u += xw[(e >> 1) + q] * f[10 + (e & 1) - 2 * q];
+            u *= 2.f;
+            // replicate padding of the up-sampled signal: slots whose n falls outside [0, 2L) copy the edge value
+            const int nc = min(max(n, 0), 2 * L - 1);
+            if (nc != n) {
+                const int ilo = (nc + 5) >> 1;      // recompute for the clamped index (rare: only at the two ends)
+                float uu = 0.f;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int i = ilo + q, tap = nc + 15 - 2 * i;
+                    const int sl = min(max(i - i0, 0), A1_T + 15);
+                    uu += xs[sl] * f[tap];
+                }
+                u = 2.f * uu;
+            }
+            const float sn = fast_sin(u * a);
+            as[j] = u + inv_b * sn * sn;
         }
-        u *= 2.f;
-        const float sn = sinf(u * a);
-        as[j] = u + inv_b * sn * sn;
     }
     __syncthreads();
-    const int t = t0 + threadIdx.x;
-    if (t < L) {
+    // 4 consecutive outputs per thread: y[t] = sum_j f[j] as[2 (t - t0) + j]  -> 18 consecutive slots, 16-B aligned
+    const int tl = 4 * threadIdx.x;
+    float w[20];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&as[2 * tl + 4 * q]);
+        w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int t = t0 + tl + e;
+        if (t >= L) break;
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc += f[j] * as[2 * threadIdx.x + j];
+        for (int j = 0; j < 12; ++j) acc += f[j] * w[2 * e + j];
         st1<F32>(y, base + t, acc);
     }
 }
