@@ -62,4 +62,14 @@ if "--layers" in sys.argv:
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out",
                                      f"vae_layers_{which}.json" if which == "encode" else "vae_layers.json"), "w"))
     tot_t = sum(o["us"] for o in out); tot_f = sum(o["flops"] for o in out); tot_b = sum(o["bytes"] for o in out)
+    if "--md" in sys.argv:
+        md = sys.argv[sys.argv.index("--md") + 1]
+        with open(md, "a") as f:
+            f.write(f"\n## {which}, B={B} ({B * 10} s of stereo 44.1 kHz audio), {'bf16' if half else 'fp32'} activations\n\n"
+                    f"{len(out)} conv launches, {tot_t/1e3:.1f} ms ({B*10/(tot_t/1e6):.0f} audio-s/s), {tot_f/tot_t/1e6:.1f} TFLOP/s fp32 "
+                    f"vector (peak 157.3), {tot_b/tot_t/1e3:.0f} GB/s algorithmic HBM (peak ~8000)\n\n"
+                    "| kernel | Cin -> Cout | k | stride | dil | Lout | us | fp32 TFLOP/s | algorithmic GB/s |\n|---|---|---|---|---|---|---|---|---|\n")
+            for o in out:
+                f.write(f"| {o['kind']} | {o['Cin']} -> {o['Cout']} | {o['K']} | {o['stride']} | {o['dil']} | {o['Lout']} | {o['us']:.0f} | "
+                        f"{o['TFLOPs']:.1f} | {o['GBps']:.0f} |\n")
     print(f"{which} B={B}: {len(out)} conv launches, {tot_t/1e3:.1f} ms, {tot_f/tot_t/1e6:.1f} TFLOP/s, {tot_b/tot_t/1e3:.0f} GB/s algorithmic")
