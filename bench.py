@@ -213,8 +213,9 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(depth=args.cpu_depth)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
