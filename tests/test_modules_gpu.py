@@ -533,3 +533,34 @@ def test_full_size_dit_step_properties(dev):
     before = tr.train_step(model, lat, t, noise, cond, objective="v").item()   # loss, then the first update
     after = tr.train_step(model, lat, t, noise, cond, objective="v").item()
     assert after < before
+
+
+@pytest.mark.gpu
+def test_train_offline_example_runs_and_resumes(dev, tmp_path):
+    """examples/train_offline_hip.py: the reference's experiment-YAML schema end to end (tiny Llama, synthetic batches):
+    trains, writes `output/epoch_0_step_N.pt` with the reference's state-dict keys, resumes from it"""
+    import json
+    import subprocess
+    import yaml
+    lc = gu.LLASA_CONFIG
+    d = tmp_path / "llama"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(lc["llama"], model_type="llama")))
+    cfg = {"project_name": "t", "exp_dir": str(tmp_path / "exp"), "lr": "1e-3", "weight_decay": "0.01", "warmup_steps": 2,
+           "total_steps": 100, "gradient_accumulation_steps": 2, "save_interval": 3, "log_interval": 1,
+           "audio_loss_weight": 1.0, "end_loss_weight": 0.5, "use_flash_attation": False, "tokenizer_len": 310,
+           "model": {"llm_model_name_or_path": str(d), "latent_dim": lc["latent_dim"], "audio_proj_dim": 128}}
+    y = tmp_path / "exp.yaml"
+    y.write_text(yaml.safe_dump(cfg))
+    script = os.path.join(HERE, "..", "examples", "train_offline_hip.py")
+    for run in range(2):
+        r = subprocess.run([sys.executable, script, "--config", str(y), "--steps", "3", "--synthetic", "2", "64"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "audio_loss" in r.stdout
+    out = tmp_path / "exp" / "t" / "output"
+    assert sorted(os.listdir(out)) == ["epoch_0_step_3.pt", "epoch_0_step_6.pt"]
+    assert "resumed from" in r.stdout
+    sd = torch.load(out / "epoch_0_step_6.pt", map_location="cpu")
+    inv = json.load(open(os.path.join(G, "state_dict_keys.json")))["llasa"]
+    assert {k: list(v.shape) for k, v in sd.items()} == inv
