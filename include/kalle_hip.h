@@ -267,6 +267,10 @@ int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed
  */
 /* out = a x + b y, fp32   (fixed-sigma sampling x = mean + std * randn, model_sigmaVAE.py:150-166) */
 int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream);
+/* one-row GEMM for decoding against a KV cache: y[n] = sum_k W[n][k] x[k] (+ residual[n]); x bf16 [K], W bf16 [N][ldw],
+ * y bf16 or fp32 [N], residual fp32 [N] or NULL; K % 8 == 0, K <= 32768 */
+int kalle_gemv_bf16(const void* x, const void* W, int64_t ldw, void* y, int y_dtype, const float* residual, int N, int K,
+                    void* stream);
 /* waveform -> int16 PCM as the inference scripts write it (infer_0723.py:293): out = int16(clamp(x / max|x|, -1, 1) * 32767);
  * peak: one fp32 of device scratch that receives max|x|; x fp32 or bf16 */
 int kalle_peak_normalize_int16(const void* x, int dtype, float* peak, int16_t* out, int64_t n, void* stream);

@@ -21,6 +21,49 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
         out[i] = a * x[i] + b * y[i];
 }
 
+// single-row GEMM for KV-cached decoding (model_sigmaVAE.py:122-146 with a cache): y[n] = sum_k W[n][k] x[k] (+ residual[n]).
+// Pure weight streaming: a wave owns 2 weight rows, its lanes walk K in 16-byte chunks (x staged once per workgroup in
+// LDS), shuffle-reduce, lane 0 writes.  8 rows per 256-thread workgroup -> N/8 workgroups keep every HBM channel busy.
+template <bool YF32>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, int64_t ldw,
+                                                   void* __restrict__ y, const float* __restrict__ res, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(gsm);
+    for (int i = threadIdx.x; i < (K >> 3); i += 256)
+        reinterpret_cast<i32x4*>(xs)[i] = reinterpret_cast<const i32x4*>(x)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 8 + wave * 2;
+    if (n0 >= N) return;
+    const bool two = n0 + 1 < N;
+    const bf16_t* w0 = W + (int64_t)n0 * ldw;
+    const bf16_t* w1 = W + (int64_t)(two ? n0 + 1 : n0) * ldw;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane; c < (K >> 3); c += 64) {
+        const i32x4 xv = reinterpret_cast<const i32x4*>(xs)[c];
+        const i32x4 u = *reinterpret_cast<const i32x4*>(w0 + 8 * c);
+        const i32x4 v = *reinterpret_cast<const i32x4*>(w1 + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = bf16lo((uint32_t)xv[e]), x1 = bf16hi((uint32_t)xv[e]);
+            a0 += bf16lo((uint32_t)u[e]) * x0 + bf16hi((uint32_t)u[e]) * x1;
+            a1 += bf16lo((uint32_t)v[e]) * x0 + bf16hi((uint32_t)v[e]) * x1;
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+        if (res) { a0 += res[n0]; if (two) a1 += res[n0 + 1]; }
+        if constexpr (YF32) {
+            static_cast<float*>(y)[n0] = a0;
+            if (two) static_cast<float*>(y)[n0 + 1] = a1;
+        } else {
+            static_cast<bf16_t*>(y)[n0] = f32_to_bf16(a0);
+            if (two) static_cast<bf16_t*>(y)[n0 + 1] = f32_to_bf16(a1);
+        }
+    }
+}
+
 // peak normalisation to int16 (infer_0723.py:293: x / max|x| -> clamp(-1, 1) * 32767 -> int16, truncating like .to(int16))
 template <bool F32>
 __global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ x, unsigned* __restrict__ peak_bits, int64_t n) {
@@ -173,6 +216,21 @@ __global__ __launch_bounds__(256) void gauss_kl_bwd_kernel(const float* __restri
 extern "C" int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream) {
     if (!x || !y || !out || n <= 0) return KALLE_ERR_ARG;
     KALLE_LAUNCH(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, out, a, b, n);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_gemv_bf16(const void* x, const void* W, int64_t ldw, void* y, int y_dtype, const float* residual,
+                               int N, int K, void* stream) {
+    if (!x || !W || !y || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || K > 32768) return KALLE_ERR_ARG;
+    if (y_dtype != KALLE_F32 && y_dtype != KALLE_BF16) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((N + 7) / 8);
+    if (y_dtype == KALLE_F32)
+        KALLE_LAUNCH((gemv_kernel<true>), grid, dim3(256), (size_t)K * 2, st, static_cast<const bf16_t*>(x),
+                     static_cast<const bf16_t*>(W), ldw, y, residual, N, K);
+    else
+        KALLE_LAUNCH((gemv_kernel<false>), grid, dim3(256), (size_t)K * 2, st, static_cast<const bf16_t*>(x),
+                     static_cast<const bf16_t*>(W), ldw, y, residual, N, K);
     return kalle_check_launch();
 }
 

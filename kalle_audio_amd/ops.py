@@ -51,6 +51,14 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     ar, ac = _rows2d(a)
     br, bc = _rows2d(b)
+    if (ar == 1 and not a_kmajor and not b_kmajor and out is None and bias is None and gate is None and not glu_mode
+            and row_mask is None and not accumulate and alpha == 1.0 and M is None and N is None and K is None
+            and ac % 8 == 0 and ac <= 32768 and (residual is None or residual.is_contiguous())):
+        # single row (decoding against the KV cache): weight-streaming kernel instead of a 128-row MFMA tile
+        y = torch.empty((1, br), device=a.device, dtype=out_dtype)
+        check(lib.kalle_gemv_bf16(_p(a), _p(b), b.stride(-2) if b.dim() >= 2 else bc, _p(y), _dt(y), _p(residual), br, ac,
+                                  _stream()), "kalle_gemv_bf16")
+        return y
     if M is None:
         M = ac if a_kmajor else ar
     if K is None:

@@ -562,3 +562,17 @@ def test_peak_normalize_int16_and_axpby_inplace(ops, dev):
     want = 0.9 * a + 0.1 * b
     ops.axpby(a, b, 0.9, 0.1, out=a)
     assert torch.allclose(a, want, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(3072, 2048), (2048, 8192), (130, 72), (17, 8)])
+def test_gemv_single_row(ops, dev, N, K):
+    """the M = 1 path of ops.gemm (decoding against the KV cache): same result as the MFMA GEMM on a padded problem"""
+    x = _mk((1, K), dev, seed=95).bfloat16()
+    w = (_mk((N, K), dev, seed=96) * 0.1).bfloat16()
+    res = _mk((1, N), dev, seed=97)
+    ref = x.float() @ w.float().T
+    got = ops.gemm(x, w)
+    assert got.dtype == torch.bfloat16 and rel_l2(got, ref) < 4e-3
+    got = ops.gemm(x, w, out_dtype=torch.float32, residual=res)
+    assert rel_l2(got, ref + res) < 1e-5
