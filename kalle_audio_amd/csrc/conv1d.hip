@@ -797,9 +797,10 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
                 }
             }
         } else if (Cout > 4) {                           // stride 2 / 4 / 8: de-interleaved staging, 1024/stride positions
+            const bool wide = Cout >= 64;
             if (stride == 2) KALLE_CONV_V2(8, 8, 4, 8, 1088);
-            if (stride == 4) KALLE_CONV_V2(8, 4, 4, 8, 1088);
-            if (stride == 8 && (int64_t)Lout * B <= 1024) KALLE_CONV_V2(8, 2, 4, 8, 1088);   // longer: fallback kernel is faster
+            if (stride == 4) { if (wide) KALLE_CONV_V2(16, 4, 4, 8, 1088); else KALLE_CONV_V2(8, 4, 4, 8, 1088); }
+            if (stride == 8 && (int64_t)Lout * B <= 1024) KALLE_CONV_V2(8, 2, 4, 8, 1088);   // longer: fallback is faster
         }
 #undef KALLE_CONV_V2
     }
