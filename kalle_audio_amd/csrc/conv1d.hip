@@ -547,6 +547,195 @@ __global__ __launch_bounds__(256) void convT1d_v2_kernel(ConvParams p) {
                                                         wave, wave / WCO);
 }
 
+// ------------------------------------------------------------------------------------------------ few positions, many channels
+// The top of the VAE (C = 512 .. 2048 at a few hundred to a few thousand positions - all of a single-clip decode) does not
+// have enough positions to fill 256 CUs with the position-per-lane tiling above.  Here the roles are swapped: a LANE owns 4
+// output channels (a wave 256 of them) and 16 consecutive positions live in its accumulators; the weights of a (ci, tap)
+// step are then a coalesced 16-byte-per-lane VECTOR load from the packed [Cin][K][CoutP] array (prefetched 4 steps ahead,
+// counted vmcnt), and the 16 input values of the step are wave-uniform: ONE scalar load from a zero-padded, already
+// activated copy of x (kalle_conv_pad_act), fed to v_pk_fma_f32 as SGPR pairs.  No LDS, no barriers, waves independent.
+__global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ x, float* __restrict__ xp, int C, int Lin,
+                                                      int Lp, int pad, int act, const float* __restrict__ aa,
+                                                      const float* __restrict__ ab, int logscale, float act_param) {
+    const int row = blockIdx.y;                     // b * C + c
+    const int c = row % C;
+    float a = act_param, inv_b = 0.f;
+    if (act == 1) {
+        a = aa[c];
+        float bb = ab[c];
+        if (logscale) { a = __expf(a); bb = __expf(bb); }
+        inv_b = 1.f / (bb + 1e-9f);
+    }
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Lp; j += gridDim.x * 256) {
+        const int li = j - pad;
+        float v = 0.f;
+        if (li >= 0 && li < Lin) {
+            v = x[(int64_t)row * Lin + li];
+            if (act) v = act_apply(v, act, a, inv_b);
+        }
+        xp[(int64_t)row * Lp + j] = v;
+    }
+}
+
+struct ConvCParams {
+    const float* xp; const float* w; const float* bias; const float* res; float* y;
+    int B, Cin, Lp, Cout, CoutP, Lout, K, dil, post;
+    int split;           // 1, 2 or 4 waves of a workgroup share one position tile and split the input channels
+    // geometry of one pass: conv (nphase 1, taps K, weight row k, x offset k * dil, output l) or one phase r of a transposed
+    // conv (taps ceil((K - r) / S), weight row r + m * S, x offset -m, output q * S + r - pad)
+    int nphase, npos, xtap, ostride, opad, xlead;
+    float out_scale;
+    int pact; const float* paa; const float* pab; int plogscale; float pparam;
+};
+
+__global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
+    constexpr int P = 16, D = 4;                    // positions per wave, weight prefetch depth
+    __shared__ float red[3 * 64 * 64];              // partial accumulators of the input-channel splits (48 KiB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int S = p.split;                          // waves per position tile
+    const int sp = wave % S;                        // this wave's input-channel slice
+    const int ph = blockIdx.x % p.nphase;           // output phase (transposed conv), 0 otherwise
+    const int l0 = ((blockIdx.x / p.nphase) * (4 / S) + wave / S) * P;   // first (input-side) position of the tile
+    const bool live = l0 < p.npos;                  // (whole tile groups stay together: sp-waves of a tile share `live`)
+    const int co = blockIdx.y * 256 + 4 * lane;
+    const int cw = min(co, p.CoutP - 4);            // clamped weight column (lanes past Cout are never stored)
+    const int cper = (p.Cin + S - 1) / S;
+    const int ci_lo = min(sp * cper, p.Cin), ci_hi = min(ci_lo + cper, p.Cin);
+    const int kt = p.nphase == 1 ? p.K : (ph < p.K ? (p.K - ph + p.nphase - 1) / p.nphase : 0);   // taps of this pass
+    const int wstep = p.nphase;                     // weight k advance per tap (1 for a conv)
+    const int T = live ? (ci_hi - ci_lo) * kt : 0;
+    const int64_t oo = p.nphase == 1 ? 0 : ph - p.opad;   // output index of position q: q * ostride + oo
+
+    f32x2 acc[4][P / 2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) acc[c][j] = f32x2{0.f, 0.f};
+    if (p.res && sp == 0 && live) {                 // residual straight into the accumulators (clamped, branch-free)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* rp = p.res + ((int64_t)b * p.Cout + min(co + c, p.Cout - 1)) * p.Lout;
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) {
+                const int64_t la = (int64_t)(l0 + 2 * j) * p.ostride + oo, lb = la + p.ostride;
+                acc[c][j] = f32x2{rp[min(max(la, (int64_t)0), (int64_t)p.Lout - 1)],
+                                  rp[min(max(lb, (int64_t)0), (int64_t)p.Lout - 1)]};
+            }
+        }
+    }
+
+    // weight row of step t = (ci, m): ci * K + ph + m * wstep;  x row offset: ci * Lp + xlead + m * xtap.  Both are walked
+    // with running scalar pointers (adds only - recomputing them from (ci, m) costs ~40 scalar instructions per step)
+    const cfloat_p xb = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.xp)) + (int64_t)b * p.Cin * p.Lp + l0;
+    int64_t xoff = (int64_t)ci_lo * p.Lp + p.xlead;
+    const int64_t xwrap = (int64_t)p.Lp - (int64_t)(kt - 1) * p.xtap;
+    int k_n = 0;
+    auto xoff_next = [&]() {
+        const int64_t o = xoff;
+        if (++k_n == kt) { k_n = 0; xoff += xwrap; } else xoff += p.xtap;
+        return o;
+    };
+    const float* wrow = p.w + ((int64_t)ci_lo * p.K + min(ph, p.K - 1)) * p.CoutP;      // uniform
+    const float* const wlast = p.w + ((int64_t)p.Cin * p.K - 1) * p.CoutP;
+    const int64_t wtap = (int64_t)wstep * p.CoutP, wwrap = ((int64_t)p.K - (int64_t)(kt - 1) * wstep) * p.CoutP;
+    int k_w = 0;
+    auto wload = [&]() {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + cw);
+        if (++k_w >= kt) { k_w = 0; wrow += wwrap; } else wrow += wtap;
+        if (wrow > wlast) wrow = wlast;              // prefetch past the last step: clamped, unused
+        return v;
+    };
+    f32x4 wq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) wq[d] = wload();
+    f32x2 xa[P / 2], xn[P / 2];
+    auto xload = [&](f32x2 (&xv)[P / 2], int64_t off) {
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) xv[j] = f32x2{xb[off + 2 * j], xb[off + 2 * j + 1]};
+    };
+    auto fma = [&](const f32x4& wv, const f32x2 (&xv)[P / 2]) {
+        const f32x2 w01 = f32x2{wv[0], wv[1]}, w23 = f32x2{wv[2], wv[3]};
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0][j]) : "v"(w01), "s"(xv[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[1][j]) : "v"(w01), "s"(xv[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[2][j]) : "v"(w23), "s"(xv[j]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[3][j]) : "v"(w23), "s"(xv[j]));
+        }
+    };
+    if (T > 0) xload(xa, xoff_next());
+    // steps in groups of D so the prefetch slots are static registers; x double-buffered by name (two steps per pair)
+    auto step = [&](int t, int slot, f32x2 (&xc)[P / 2], f32x2 (&xnext)[P / 2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): x of this step is here
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) xload(xnext, xoff_next());
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        // weights of this step (3 younger loads may fly)
+        const f32x4 wv = wq[slot];
+        wq[slot] = wload();
+        fma(wv, xc);
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 4 <= T; t += 4) {
+        step(t, 0, xa, xn);
+        step(t + 1, 1, xn, xa);
+        step(t + 2, 2, xa, xn);
+        step(t + 3, 3, xn, xa);
+    }
+    if (t < T) { step(t, 0, xa, xn); ++t; }
+    if (t < T) { step(t, 1, xn, xa); ++t; }
+    if (t < T) { step(t, 2, xa, xn); ++t; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (S > 1) {                                    // fold the input-channel slices: slice 0 of each tile collects
+        const int tile = wave / S;
+        if (sp > 0) {
+            float* rp = red + ((tile * (S - 1) + sp - 1) * 64) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < P; ++j) rp[(c * P + j) * 64] = acc[c][j >> 1][j & 1];
+        }
+        __syncthreads();
+        if (sp > 0) return;
+        for (int q = 0; q < S - 1; ++q) {
+            const float* rp = red + ((tile * (S - 1) + q) * 64) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < P; ++j) acc[c][j >> 1][j & 1] += rp[(c * P + j) * 64];
+        }
+    }
+    if (!live) return;
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cc = co + c;
+        if (cc >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[cc] : 0.f;
+        float pa = p.pparam, pinv_b = 0.f;
+        if (p.pact == 1) {
+            pa = p.paa[cc];
+            float bb = p.pab[cc];
+            if (p.plogscale) { pa = __expf(pa); bb = __expf(bb); }
+            pinv_b = 1.f / (bb + 1e-9f);
+        }
+        float* yp = p.y + ((int64_t)b * p.Cout + cc) * p.Lout;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int64_t l = (int64_t)(l0 + j) * p.ostride + oo;
+            if (l < 0 || l >= p.Lout) continue;
+            float v = (acc[c][j >> 1][j & 1] + bv) * p.out_scale;   // (residual already inside acc)
+            if (p.post & 2) v += yp[l];
+            if (p.pact) v = act_apply(v, p.pact, pa, pinv_b);
+            if (p.post & 1) v = tanhf(v);
+            yp[l] = v;
+        }
+    }
+}
+
 // weight norm fold + repack to [Cin][K][CoutP] (CoutP = Cout rounded up to 8, pad columns zeroed). One workgroup per index of dim 0 of v (the weight_norm dim).
 //   conv:  v [Cout][Cin][K], g [Cout]  -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co]||
 //   convT: v [Cin][Cout][K], g [Cin]   -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci]||
@@ -810,6 +999,70 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     else if (xf) KALLE_LAUNCH((conv1d_kernel<true, false>), grid, block, 0, st, p);
     else if (yf) KALLE_LAUNCH((conv1d_kernel<false, true>), grid, block, 0, st, p);
     else KALLE_LAUNCH((conv1d_kernel<false, false>), grid, block, 0, st, p);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_conv_pad_len(int Lout, int ksize, int dilation) {
+    return ((Lout + 15) & ~15) + (ksize - 1) * dilation;
+}
+
+extern "C" int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding,
+                                  const kalle_act* act, void* stream) {
+    if (!x || !x_padded || B <= 0 || C <= 0 || Lin <= 0 || Lp <= 0 || padding < 0 || (int64_t)B * C > 65535) return KALLE_ERR_ARG;
+    ActArgs a;
+    if (!read_act(act, a, false)) return KALLE_ERR_ARG;
+    KALLE_LAUNCH(pad_act_kernel, dim3((Lp + 255) / 256 > 64 ? 64 : (Lp + 255) / 256, B * C), dim3(256), 0,
+                 static_cast<hipStream_t>(stream), x, x_padded, C, Lin, Lp, padding, a.code, a.alpha, a.beta, a.logscale, a.param);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y, int B,
+                                       int Cin, int Lp, int Cout, int Lout, int ksize, int dilation,
+                                       const kalle_conv_epilogue* epi, void* stream) {
+    if (!x_padded || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0 || dilation <= 0)
+        return KALLE_ERR_ARG;
+    if (Lp < kalle_conv_pad_len(Lout, ksize, dilation) || B > 65535) return KALLE_ERR_ARG;
+    ConvParams q{};
+    if (!fill_params(q, nullptr, epi)) return KALLE_ERR_ARG;
+    // waves without splitting the input channels; aim for >= 2048 (two per SIMD)
+    const int64_t waves = (int64_t)((Lout + 15) / 16) * ((Cout + 255) / 256) * B;
+    const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
+    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
+                  dilation, q.post, split, 1, Lout, dilation, 1, 0, 0, q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
+    if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
+    const int tiles_per_wg = 4 / split;
+    dim3 grid(((Lout + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg, (Cout + 255) / 256, B);
+    KALLE_LAUNCH(conv1d_cfirst_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_convT_pad_len(int Lout, int ksize, int stride, int padding) {
+    const int nq = (Lout - 1 + padding) / stride + 1, mmax = (ksize + stride - 1) / stride;
+    return ((nq + 15) & ~15) + mmax - 1;
+}
+
+extern "C" int kalle_conv_transpose1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y,
+                                                 int B, int Cin, int Lp, int Cout, int Lout, int ksize, int stride,
+                                                 int padding, const kalle_conv_epilogue* epi, void* stream) {
+    if (!x_padded || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0 || stride <= 0 ||
+        padding < 0)
+        return KALLE_ERR_ARG;
+    if (Lp < kalle_convT_pad_len(Lout, ksize, stride, padding) || B > 65535) return KALLE_ERR_ARG;
+    ConvParams q{};
+    if (!fill_params(q, nullptr, epi)) return KALLE_ERR_ARG;
+    const int nq = (Lout - 1 + padding) / stride + 1, mmax = (ksize + stride - 1) / stride;
+    const int64_t waves = (int64_t)((nq + 15) / 16) * ((Cout + 255) / 256) * B * stride;
+    const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
+    // x_padded has mmax-1 leading zeros: tap m of input position q reads slot q + (mmax-1) - m
+    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
+                  1, q.post, split, stride, nq, -1, stride, padding, mmax - 1, q.out_scale, q.pact, q.paa, q.pab, q.plogscale,
+                  q.pparam};
+    if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
+    const int tiles_per_wg = 4 / split;
+    const int64_t gx = (int64_t)(((nq + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg) * stride;
+    if (gx > 0x7fffffff) return KALLE_ERR_ARG;
+    dim3 grid((unsigned)gx, (Cout + 255) / 256, B);
+    KALLE_LAUNCH(conv1d_cfirst_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return kalle_check_launch();
 }
 

@@ -576,3 +576,58 @@ def test_gemv_single_row(ops, dev, N, K):
     assert got.dtype == torch.bfloat16 and rel_l2(got, ref) < 4e-3
     got = ops.gemm(x, w, out_dtype=torch.float32, residual=res)
     assert rel_l2(got, ref + res) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,K,dil,L,act", [(64, 256, 7, 1, 215, 0), (96, 520, 7, 9, 333, 1), (128, 300, 1, 1, 77, 2),
+                                                  (40, 256, 3, 3, 1000, 1), (1024, 1024, 7, 3, 100, 1)])
+def test_conv1d_channels_per_lane_kernel(ops, dev, Cin, Cout, K, dil, L, act, monkeypatch):
+    """the few-positions / many-channels kernel (pad+activate pass, then lane = 4 output channels): forced on, against torch"""
+    from kalle_audio_amd import conv_ops
+    monkeypatch.setenv("KALLE_CONV_CFIRST", "1")
+    B = 2
+    pad = dil * (K - 1) // 2
+    x = _mk((B, Cin, L), dev, seed=110)
+    w = _mk((Cout, Cin, K), dev, seed=111) / (Cin * K) ** 0.5
+    bias = _mk((Cout,), dev, seed=112)
+    alpha, beta = 0.3 * _mk((Cin,), dev, seed=113), 0.3 * _mk((Cin,), dev, seed=114)
+    pa, pb = 0.3 * _mk((Cout,), dev, seed=115), 0.3 * _mk((Cout,), dev, seed=116)
+    res = _mk((B, Cout, L), dev, seed=117)
+    xa = x
+    if act == 1:
+        xa = x + torch.sin(x * alpha.exp()[None, :, None]) ** 2 / (beta.exp()[None, :, None] + 1e-9)
+    elif act == 2:
+        xa = F.elu(x)
+    r = F.conv1d(xa, w, bias, padding=pad, dilation=dil) + res
+    ref = r + torch.sin(r * pa.exp()[None, :, None]) ** 2 / (pb.exp()[None, :, None] + 1e-9)
+    wp = conv_ops.weight_norm_fold(w, None)
+    got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, padding=pad, dilation=dil, act=act, alpha=alpha, beta=beta,
+                          residual=res, post_act=(1, pa, pb, True, 0.0))
+    assert rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
+    y0 = _mk((B, Cout, L), dev, seed=118)
+    acc = y0.clone()
+    got = conv_ops.conv1d(x, wp, None, Cout=Cout, K=K, padding=pad, dilation=dil, out_scale=0.5, accumulate_into=acc, post=1)
+    assert rel_l2(got, torch.tanh(y0 + 0.5 * F.conv1d(x, w, None, padding=pad, dilation=dil))) < 3e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,stride,L,trim", [(64, 256, 8, 27, 0), (96, 300, 4, 130, 0), (128, 256, 2, 77, 2),
+                                                    (40, 264, 5, 33, 0), (2048, 1024, 8, 20, 0)])
+def test_conv_transpose1d_channels_per_lane_kernel(ops, dev, Cin, Cout, stride, L, trim, monkeypatch):
+    from kalle_audio_amd import conv_ops
+    monkeypatch.setenv("KALLE_CONV_CFIRST", "1")
+    B = 2
+    K = 2 * stride + stride % 2
+    pad = 0 if trim else math.ceil(stride / 2)
+    x = _mk((B, Cin, L), dev, seed=120)
+    w = _mk((Cin, Cout, K), dev, seed=121) / (Cin * 2) ** 0.5
+    bias = _mk((Cout,), dev, seed=122)
+    alpha, beta = 0.3 * _mk((Cin,), dev, seed=123), 0.3 * _mk((Cin,), dev, seed=124)
+    xa = x + torch.sin(x * alpha.exp()[None, :, None]) ** 2 / (beta.exp()[None, :, None] + 1e-9)
+    ref = F.conv_transpose1d(xa, w, bias, stride=stride, padding=pad)
+    if trim:
+        ref = ref[:, :, :-trim]
+    wp = conv_ops.weight_norm_fold(w, None, transposed=True)
+    got = conv_ops.conv_transpose1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=1, alpha=alpha, beta=beta,
+                                    trim=trim)
+    assert got.shape == ref.shape and rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
