@@ -259,14 +259,16 @@ int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const fl
 /* Few positions, many channels (the C >= 512 top of the VAE; all of a single-clip decode): stride-1 conv with the roles of
  * lanes and registers swapped (lane = 4 output channels, 16 positions in registers, weights as coalesced vector loads, the
  * step's inputs as one scalar load).  Two calls: kalle_conv_pad_act writes act(x) into a zero-padded fp32 copy
- * x_padded [B][C][Lp] (left pad = `padding`, Lp >= kalle_conv_pad_len(Lout, ksize, dilation)), kalle_conv1d_cfirst_fwd
- * convolves it (same epilogue struct as kalle_conv1d_fwd; fp32 only).  The caller owns x_padded. */
-int kalle_conv_pad_len(int Lout, int ksize, int dilation);
+ * x_padded [B][C][Lp] (`padding` leading zeros, Lp = kalle_conv_pad_len(...)), kalle_conv1d_cfirst_fwd convolves it (same
+ * epilogue struct as kalle_conv1d_fwd; fp32 only).  Strided convs (dilation 1): pass phases = stride and padding =
+ * ceil(padding / stride) * stride to kalle_conv_pad_act - the copy is then de-interleaved into `stride` phase rows so that a
+ * tap's inputs for consecutive outputs are consecutive.  The caller owns x_padded. */
+int kalle_conv_pad_len(int Lout, int ksize, int stride, int padding, int dilation);
 int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding, const kalle_act* act,
-                       void* stream);
+                       int phases, void* stream);
 int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y, int B, int Cin,
-                            int Lp, int Cout, int Lout, int ksize, int dilation, const kalle_conv_epilogue* epi,
-                            void* stream);
+                            int Lp, int Cout, int Lout, int ksize, int stride, int padding, int dilation,
+                            const kalle_conv_epilogue* epi, void* stream);
 /* the same for a transposed conv (one pass per output phase): x_padded [B][C][Lp] = kalle_conv_pad_act(x, padding =
  * ceil(ksize / stride) - 1), Lp >= kalle_convT_pad_len(Lout, ksize, stride, padding) */
 int kalle_convT_pad_len(int Lout, int ksize, int stride, int padding);

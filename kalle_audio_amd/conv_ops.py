@@ -58,15 +58,16 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
     # few positions, many channels (the top of the VAE, all of a single-clip decode): channels-per-lane kernel over a padded,
     # pre-activated copy of x.  Chosen when the position-per-lane tiling would leave most CUs without a workgroup.
     want = os.environ.get("KALLE_CONV_CFIRST")
-    small = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B < 256 and Cout >= 256
-    if (stride == 1 and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
+    small = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B < 256 and (Cout >= 256 or (Cout >= 64 and Lout * B <= 1024))
+    if ((stride == 1 or dilation == 1) and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
             and (want == "1" or (want is None and small))):
-        Lp = lib.kalle_conv_pad_len(Lout, K, dilation)
+        Lp = lib.kalle_conv_pad_len(Lout, K, stride, padding, dilation)
+        lead = padding if stride == 1 else (padding + stride - 1) // stride * stride
         xp = torch.empty((B, Cin, Lp), device=x.device, dtype=torch.float32)
-        check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, padding, ctypes.addressof(ia), _stream()),
+        check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, lead, ctypes.addressof(ia), stride, _stream()),
               "kalle_conv_pad_act")
-        check(lib.kalle_conv1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, dilation,
-                                          ctypes.addressof(ep), _stream()), "kalle_conv1d_cfirst_fwd")
+        check(lib.kalle_conv1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, stride, padding,
+                                          dilation, ctypes.addressof(ep), _stream()), "kalle_conv1d_cfirst_fwd")
         return y
     check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout, Lout, K, stride,
                                padding, dilation, ctypes.addressof(ia), ctypes.addressof(ep), _stream()),
@@ -90,7 +91,7 @@ def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alph
     if act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32 and (want == "1" or (want is None and small)):
         Lp = lib.kalle_convT_pad_len(Lout, K, stride, padding)
         xp = torch.empty((B, Cin, Lp), device=x.device, dtype=torch.float32)
-        check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, (K + stride - 1) // stride - 1, ctypes.addressof(ia),
+        check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, (K + stride - 1) // stride - 1, ctypes.addressof(ia), 1,
                                      _stream()), "kalle_conv_pad_act")
         check(lib.kalle_conv_transpose1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, stride,
                                                     padding, ctypes.addressof(ep), _stream()),

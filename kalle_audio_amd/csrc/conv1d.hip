@@ -554,9 +554,12 @@ __global__ __launch_bounds__(256) void convT1d_v2_kernel(ConvParams p) {
 // step are then a coalesced 16-byte-per-lane VECTOR load from the packed [Cin][K][CoutP] array (prefetched 4 steps ahead,
 // counted vmcnt), and the 16 input values of the step are wave-uniform: ONE scalar load from a zero-padded, already
 // activated copy of x (kalle_conv_pad_act), fed to v_pk_fma_f32 as SGPR pairs.  No LDS, no barriers, waves independent.
+// phases > 1 (strided conv): padded index j is stored at (j % phases) * (Lp / phases) + j / phases, so the inputs of a tap
+// for consecutive outputs are consecutive
 __global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ x, float* __restrict__ xp, int C, int Lin,
                                                       int Lp, int pad, int act, const float* __restrict__ aa,
-                                                      const float* __restrict__ ab, int logscale, float act_param) {
+                                                      const float* __restrict__ ab, int logscale, float act_param,
+                                                      int phases) {
     const int row = blockIdx.y;                     // b * C + c
     const int c = row % C;
     float a = act_param, inv_b = 0.f;
@@ -573,7 +576,8 @@ __global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ 
             v = x[(int64_t)row * Lin + li];
             if (act) v = act_apply(v, act, a, inv_b);
         }
-        xp[(int64_t)row * Lp + j] = v;
+        const int slot = phases == 1 ? j : (j % phases) * (Lp / phases) + j / phases;
+        xp[(int64_t)row * Lp + slot] = v;
     }
 }
 
@@ -584,6 +588,7 @@ struct ConvCParams {
     // geometry of one pass: conv (nphase 1, taps K, weight row k, x offset k * dil, output l) or one phase r of a transposed
     // conv (taps ceil((K - r) / S), weight row r + m * S, x offset -m, output q * S + r - pad)
     int nphase, npos, xtap, ostride, opad, xlead;
+    int xS, xLq, xph0;   // strided conv: input phases, phase-row length, phase of tap 0 (xS = 1 otherwise)
     float out_scale;
     int pact; const float* paa; const float* pab; int plogscale; float pparam;
 };
@@ -630,11 +635,15 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
     // with running scalar pointers (adds only - recomputing them from (ci, m) costs ~40 scalar instructions per step)
     const cfloat_p xb = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.xp)) + (int64_t)b * p.Cin * p.Lp + l0;
     int64_t xoff = (int64_t)ci_lo * p.Lp + p.xlead;
-    const int64_t xwrap = (int64_t)p.Lp - (int64_t)(kt - 1) * p.xtap;
-    int k_n = 0;
+    const int nwr = p.xS > 1 ? (p.xph0 + kt - 1) / p.xS : 0;          // phase wraps among a channel's kt-1 tap advances
+    const int64_t xphw = 1 - (int64_t)(p.xS - 1) * p.xLq;
+    const int64_t xwrap = (int64_t)p.Lp - (p.xS > 1 ? (int64_t)(kt - 1 - nwr) * p.xLq + nwr * xphw : (int64_t)(kt - 1) * p.xtap);
+    int k_n = 0, ph_x = p.xph0;
     auto xoff_next = [&]() {
         const int64_t o = xoff;
-        if (++k_n == kt) { k_n = 0; xoff += xwrap; } else xoff += p.xtap;
+        if (++k_n == kt) { k_n = 0; ph_x = p.xph0; xoff += xwrap; }
+        else if (p.xS > 1) { if (++ph_x == p.xS) { ph_x = 0; xoff += xphw; } else xoff += p.xLq; }
+        else xoff += p.xtap;
         return o;
     };
     const float* wrow = p.w + ((int64_t)ci_lo * p.K + min(ph, p.K - 1)) * p.CoutP;      // uniform
@@ -1002,33 +1011,46 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     return kalle_check_launch();
 }
 
-extern "C" int kalle_conv_pad_len(int Lout, int ksize, int dilation) {
-    return ((Lout + 15) & ~15) + (ksize - 1) * dilation;
+extern "C" int kalle_conv_pad_len(int Lout, int ksize, int stride, int padding, int dilation) {
+    if (stride == 1) return ((Lout + 15) & ~15) + (ksize - 1) * dilation;
+    const int padq = (padding + stride - 1) / stride, d = padq * stride - padding;   // phase rows of Lq slots each
+    return stride * (((Lout + 15) & ~15) + (ksize - 1 + d) / stride + 1);
 }
 
 extern "C" int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding,
-                                  const kalle_act* act, void* stream) {
-    if (!x || !x_padded || B <= 0 || C <= 0 || Lin <= 0 || Lp <= 0 || padding < 0 || (int64_t)B * C > 65535) return KALLE_ERR_ARG;
+                                  const kalle_act* act, int phases, void* stream) {
+    if (!x || !x_padded || B <= 0 || C <= 0 || Lin <= 0 || Lp <= 0 || padding < 0 || phases <= 0 || Lp % phases ||
+        (int64_t)B * C > 65535)
+        return KALLE_ERR_ARG;
     ActArgs a;
     if (!read_act(act, a, false)) return KALLE_ERR_ARG;
     KALLE_LAUNCH(pad_act_kernel, dim3((Lp + 255) / 256 > 64 ? 64 : (Lp + 255) / 256, B * C), dim3(256), 0,
-                 static_cast<hipStream_t>(stream), x, x_padded, C, Lin, Lp, padding, a.code, a.alpha, a.beta, a.logscale, a.param);
+                 static_cast<hipStream_t>(stream), x, x_padded, C, Lin, Lp, padding, a.code, a.alpha, a.beta, a.logscale, a.param,
+                 phases);
     return kalle_check_launch();
 }
 
 extern "C" int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y, int B,
-                                       int Cin, int Lp, int Cout, int Lout, int ksize, int dilation,
-                                       const kalle_conv_epilogue* epi, void* stream) {
-    if (!x_padded || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0 || dilation <= 0)
+                                       int Cin, int Lp, int Cout, int Lout, int ksize, int stride, int padding,
+                                       int dilation, const kalle_conv_epilogue* epi, void* stream) {
+    if (!x_padded || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0 || dilation <= 0 ||
+        stride <= 0 || padding < 0)
         return KALLE_ERR_ARG;
-    if (Lp < kalle_conv_pad_len(Lout, ksize, dilation) || B > 65535) return KALLE_ERR_ARG;
+    if (stride > 1 && dilation != 1) return KALLE_ERR_UNSUPPORTED;
+    if (Lp < kalle_conv_pad_len(Lout, ksize, stride, padding, dilation) || (stride > 1 && Lp % stride) || B > 65535)
+        return KALLE_ERR_ARG;
     ConvParams q{};
     if (!fill_params(q, nullptr, epi)) return KALLE_ERR_ARG;
     // waves without splitting the input channels; aim for >= 2048 (two per SIMD)
     const int64_t waves = (int64_t)((Lout + 15) / 16) * ((Cout + 255) / 256) * B;
     const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
+    // stride > 1: x_padded is de-interleaved into `stride` phase rows (left pad padq * stride): tap k of output l reads
+    // phase (k + d) % stride at slot l + (k + d) / stride
+    const int padq = (padding + stride - 1) / stride, d = padq * stride - padding;
+    const int Lq = stride > 1 ? Lp / stride : 0;
     ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
-                  dilation, q.post, split, 1, Lout, dilation, 1, 0, 0, q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
+                  dilation, q.post, split, 1, Lout, dilation, 1, 0, stride > 1 ? d * Lq : 0, stride, Lq, stride > 1 ? d : 0,
+                  q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
     const int tiles_per_wg = 4 / split;
     dim3 grid(((Lout + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg, (Cout + 255) / 256, B);
@@ -1055,8 +1077,8 @@ extern "C" int kalle_conv_transpose1d_cfirst_fwd(const float* x_padded, const fl
     const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
     // x_padded has mmax-1 leading zeros: tap m of input position q reads slot q + (mmax-1) - m
     ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
-                  1, q.post, split, stride, nq, -1, stride, padding, mmax - 1, q.out_scale, q.pact, q.paa, q.pab, q.plogscale,
-                  q.pparam};
+                  1, q.post, split, stride, nq, -1, stride, padding, mmax - 1, 1, 0, 0, q.out_scale, q.pact, q.paa, q.pab,
+                  q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
     const int tiles_per_wg = 4 / split;
     const int64_t gx = (int64_t)(((nq + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg) * stride;

@@ -581,7 +581,8 @@ def test_gemv_single_row(ops, dev, N, K):
 @pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,K,dil,L,act", [(64, 256, 7, 1, 215, 0), (96, 520, 7, 9, 333, 1), (128, 300, 1, 1, 77, 2),
                                                   (40, 256, 3, 3, 1000, 1), (1024, 1024, 7, 3, 100, 1)])
-def test_conv1d_channels_per_lane_kernel(ops, dev, Cin, Cout, K, dil, L, act, monkeypatch):
+@pytest.mark.parametrize("stride", [1])
+def test_conv1d_channels_per_lane_kernel(ops, dev, Cin, Cout, K, dil, L, act, stride, monkeypatch):
     """the few-positions / many-channels kernel (pad+activate pass, then lane = 4 output channels): forced on, against torch"""
     from kalle_audio_amd import conv_ops
     monkeypatch.setenv("KALLE_CONV_CFIRST", "1")
@@ -630,4 +631,21 @@ def test_conv_transpose1d_channels_per_lane_kernel(ops, dev, Cin, Cout, stride, 
     wp = conv_ops.weight_norm_fold(w, None, transposed=True)
     got = conv_ops.conv_transpose1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=1, alpha=alpha, beta=beta,
                                     trim=trim)
+    assert got.shape == ref.shape and rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,K,stride,pad,L", [(64, 256, 16, 8, 4, 1720), (96, 300, 8, 4, 2, 333), (40, 256, 4, 2, 1, 77),
+                                                     (24, 264, 6, 3, 2, 100), (16, 256, 8, 4, 3, 129)])
+def test_strided_conv_channels_per_lane_kernel(ops, dev, Cin, Cout, K, stride, pad, L, monkeypatch):
+    """strided convs on the channels-per-lane kernel: the padded copy of x is de-interleaved into `stride` phase rows"""
+    from kalle_audio_amd import conv_ops
+    monkeypatch.setenv("KALLE_CONV_CFIRST", "1")
+    B = 2
+    x = _mk((B, Cin, L), dev, seed=130)
+    w = _mk((Cout, Cin, K), dev, seed=131) / (Cin * K) ** 0.5
+    bias = _mk((Cout,), dev, seed=132)
+    ref = F.conv1d(F.elu(x), w, bias, stride=stride, padding=pad)
+    wp = conv_ops.weight_norm_fold(w, None)
+    got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=2)
     assert got.shape == ref.shape and rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
