@@ -248,6 +248,8 @@ typedef struct kalle_conv_epilogue {
     int32_t accumulate;
     int32_t tanh;
     kalle_act post_act;
+    void* y_raw;   /* optional second output: the value BEFORE post_act / tanh (y's shape and dtype) - a residual unit's output
+                      is needed raw by the next unit's skip path and activated by its first conv */
 } kalle_conv_epilogue;
 /* y = epilogue(conv1d(in_act(x), w, b, stride, padding, dilation)); in_act / epi may be NULL (= none / plain store).
  *   `padding` is the LEFT zero pad; the right pad is implied by Lout (symmetric padding: autoencoders.py:45,76;

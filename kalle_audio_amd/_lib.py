@@ -52,7 +52,7 @@ class Act(ctypes.Structure):
 class ConvEpilogue(ctypes.Structure):
     """Mirror of `kalle_conv_epilogue`."""
     _fields_ = [("residual", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
-                ("tanh", ctypes.c_int32), ("post_act", Act)]
+                ("tanh", ctypes.c_int32), ("post_act", Act), ("y_raw", ctypes.c_void_p)]
 
 
 _CTYPE = {

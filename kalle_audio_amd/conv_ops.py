@@ -27,15 +27,16 @@ def _act_struct(code, alpha, beta, logscale, param):
     return _lib.Act(int(code), int(bool(logscale)), _p(alpha), _p(beta), float(param))
 
 
-def _epilogue(residual, out_scale, accumulate, tanh, post_act):
-    """post_act: None or (code, alpha, beta, logscale, param) - the next layer's input activation, applied at the store"""
+def _epilogue(residual, out_scale, accumulate, tanh, post_act, y_raw=None):
+    """post_act: None or (code, alpha, beta, logscale, param) - the next layer's input activation, applied at the store;
+    y_raw: optional tensor that also receives the un-activated value"""
     pa = _act_struct(*post_act) if post_act is not None else _lib.Act(0, 0, None, None, 0.0)
-    return _lib.ConvEpilogue(_p(residual), float(out_scale), int(accumulate), int(tanh), pa)
+    return _lib.ConvEpilogue(_p(residual), float(out_scale), int(accumulate), int(tanh), pa, _p(y_raw))
 
 
 def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0, alpha=None, beta=None,
            logscale=True, residual=None, post=0, out_dtype=None, pad_right=None, act_param=0.0, out_scale=1.0,
-           accumulate_into=None, post_act=None):
+           accumulate_into=None, post_act=None, want_raw=False):
     """padding = left pad; pad_right defaults to the same (symmetric). act: 0 none, 1 snake(-beta), 2 ELU, 3 LeakyReLU,
     4 WaveNet gate.  Store: (conv + bias + residual) * out_scale (+= accumulate_into) -> post_act -> tanh (post=1)."""
     lib = _lib.load()
@@ -54,7 +55,8 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
         residual = residual.contiguous()
         assert residual.dtype == x.dtype and residual.shape == y.shape
     ia = _act_struct(act, alpha, beta, logscale, act_param)
-    ep = _epilogue(residual, out_scale, accumulate_into is not None, post & 1, post_act)
+    y_raw = torch.empty_like(y) if want_raw else None      # dual output: (post_act(y), y)
+    ep = _epilogue(residual, out_scale, accumulate_into is not None, post & 1, post_act, y_raw)
     # few positions, many channels (the top of the VAE, all of a single-clip decode): channels-per-lane kernel over a padded,
     # pre-activated copy of x.  Chosen when the position-per-lane tiling would leave most CUs without a workgroup.
     want = os.environ.get("KALLE_CONV_CFIRST")
@@ -68,15 +70,15 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
               "kalle_conv_pad_act")
         check(lib.kalle_conv1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, stride, padding,
                                           dilation, ctypes.addressof(ep), _stream()), "kalle_conv1d_cfirst_fwd")
-        return y
+        return (y, y_raw) if want_raw else y
     check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout, Lout, K, stride,
                                padding, dilation, ctypes.addressof(ia), ctypes.addressof(ep), _stream()),
           "kalle_conv1d_fwd")
-    return y
+    return (y, y_raw) if want_raw else y
 
 
 def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alpha=None, beta=None, logscale=True,
-                     out_dtype=None, trim=0, act_param=0.0, post_act=None):
+                     out_dtype=None, trim=0, act_param=0.0, post_act=None, want_raw=False):
     """trim: drop the last `trim` outputs (causal transposed conv)"""
     lib = _lib.load()
     x = x.contiguous()
@@ -84,7 +86,8 @@ def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alph
     Lout = (Lin - 1) * stride - 2 * padding + K - trim
     y = torch.empty((B, Cout, Lout), device=x.device, dtype=out_dtype or x.dtype)
     ia = _act_struct(act, alpha, beta, logscale, act_param)
-    ep = _epilogue(None, 1.0, False, False, post_act)
+    y_raw = torch.empty_like(y) if want_raw else None
+    ep = _epilogue(None, 1.0, False, False, post_act, y_raw)
     want = os.environ.get("KALLE_CONV_CFIRST")
     nq = (Lout - 1 + padding) // stride + 1
     small = ((nq + 511) // 512) * ((Cout + 63) // 64) * B * stride < 1024 and Cout >= 256
@@ -96,11 +99,11 @@ def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alph
         check(lib.kalle_conv_transpose1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, stride,
                                                     padding, ctypes.addressof(ep), _stream()),
               "kalle_conv_transpose1d_cfirst_fwd")
-        return y
+        return (y, y_raw) if want_raw else y
     check(lib.kalle_conv_transpose1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout,
                                          Lout, K, stride, padding, ctypes.addressof(ia), ctypes.addressof(ep),
                                          _stream()), "kalle_conv_transpose1d_fwd")
-    return y
+    return (y, y_raw) if want_raw else y
 
 
 def snake_beta(x, alpha, beta, logscale=True):

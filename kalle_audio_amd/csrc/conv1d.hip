@@ -63,6 +63,7 @@ struct ConvParams {
     int CoutP;  // row stride of the packed weights = Cout rounded up to 8 (pad columns are zero)
     int xC;     // channels of the x tensor (2*Cin for the gated activation, else Cin)
     int pact; const float* paa; const float* pab; int plogscale; float pparam;   // activation applied to the output
+    void* y_raw;               // dual output: the un-activated value also goes here (same shape / dtype as y)
     int nco, ntile, co_fast;   // v2 grid: blockIdx.x enumerates (position tile, channel tile), channel tile fastest if co_fast
 };
 
@@ -74,6 +75,7 @@ __device__ __forceinline__ void conv_store(const ConvParams& p, int co, int64_t 
     if (RES && p.res) v += ld1<XF32>(p.res, oi);
     v *= p.out_scale;
     if (p.post & 2) v += ld1<YF32>(p.y, oi);
+    if (p.y_raw) st1<YF32>(p.y_raw, oi, v);         // consumers that need the raw value (residual paths)
     if (p.pact) v = act_apply(v, p.pact, pa, pinv_b);
     if (p.post & 1) v = tanhf(v);
     st1<YF32>(p.y, oi, v);
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ 
 }
 
 struct ConvCParams {
-    const float* xp; const float* w; const float* bias; const float* res; float* y;
+    const float* xp; const float* w; const float* bias; const float* res; float* y; float* y_raw;
     int B, Cin, Lp, Cout, CoutP, Lout, K, dil, post;
     int split;           // 1, 2 or 4 waves of a workgroup share one position tile and split the input channels
     // geometry of one pass: conv (nphase 1, taps K, weight row k, x offset k * dil, output l) or one phase r of a transposed
@@ -738,6 +740,7 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
             if (l < 0 || l >= p.Lout) continue;
             float v = (acc[c][j >> 1][j & 1] + bv) * p.out_scale;   // (residual already inside acc)
             if (p.post & 2) v += yp[l];
+            if (p.y_raw) p.y_raw[((int64_t)b * p.Cout + cc) * p.Lout + l] = v;
             if (p.pact) v = act_apply(v, p.pact, pa, pinv_b);
             if (p.post & 1) v = tanhf(v);
             yp[l] = v;
@@ -914,10 +917,11 @@ bool fill_params(ConvParams& p, const kalle_act* in_act, const kalle_conv_epilog
     ActArgs ia, pa;
     if (!read_act(in_act, ia, true)) return false;
     p.act = ia.code; p.aa = ia.alpha; p.ab = ia.beta; p.logscale = ia.logscale; p.act_param = ia.param;
-    p.res = nullptr; p.out_scale = 1.f; p.post = 0;
+    p.res = nullptr; p.out_scale = 1.f; p.post = 0; p.y_raw = nullptr;
     if (epi) {
         if (!read_act(&epi->post_act, pa, false)) return false;
         p.res = epi->residual;
+        p.y_raw = epi->y_raw;
         p.out_scale = epi->out_scale;
         p.post = (epi->tanh ? 1 : 0) | (epi->accumulate ? 2 : 0);
     }
@@ -1048,7 +1052,7 @@ extern "C" int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_pac
     // phase (k + d) % stride at slot l + (k + d) / stride
     const int padq = (padding + stride - 1) / stride, d = padq * stride - padding;
     const int Lq = stride > 1 ? Lp / stride : 0;
-    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
+    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, static_cast<float*>(q.y_raw), B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
                   dilation, q.post, split, 1, Lout, dilation, 1, 0, stride > 1 ? d * Lq : 0, stride, Lq, stride > 1 ? d : 0,
                   q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
@@ -1076,7 +1080,7 @@ extern "C" int kalle_conv_transpose1d_cfirst_fwd(const float* x_padded, const fl
     const int64_t waves = (int64_t)((nq + 15) / 16) * ((Cout + 255) / 256) * B * stride;
     const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
     // x_padded has mmax-1 leading zeros: tap m of input position q reads slot q + (mmax-1) - m
-    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
+    ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, static_cast<float*>(q.y_raw), B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
                   1, q.post, split, stride, nq, -1, stride, padding, mmax - 1, 1, 0, 0, q.out_scale, q.pact, q.paa, q.pab,
                   q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
@@ -1133,7 +1137,7 @@ extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const floa
         }
 #undef KALLE_CONVT_V2
     }
-    if (ksize > MAX_K + 2 || ksize > 2 * stride + 1 || p.res || p.post || p.pact || p.out_scale != 1.f)
+    if (ksize > MAX_K + 2 || ksize > 2 * stride + 1 || p.res || p.post || p.pact || p.y_raw || p.out_scale != 1.f)
         return KALLE_ERR_UNSUPPORTED;
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);
     if (xf && yf) KALLE_LAUNCH((convT1d_kernel<true, true>), grid, block, 0, st, p);

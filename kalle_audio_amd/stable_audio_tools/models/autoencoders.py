@@ -75,12 +75,14 @@ class WNConv1d(_WNBase):
         self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
 
-    def forward(self, x, act=None, residual=None, post=0, post_act=None):
+    def forward(self, x, act=None, residual=None, post=0, post_act=None, want_raw=False):
+        """want_raw: also return the value before `post_act` -> (activated, raw)"""
         x = _prep(x)
         code, a, b, ls = _act_args(act)
         return conv_ops.conv1d(x, self._packed(), self._bias(), Cout=self.out_channels, K=self.kernel_size,
                                stride=self.stride, padding=self.padding, dilation=self.dilation, act=code, alpha=a,
-                               beta=b, logscale=ls, residual=residual, post=post, post_act=_post_act(post_act))
+                               beta=b, logscale=ls, residual=residual, post=post, post_act=_post_act(post_act),
+                               want_raw=want_raw)
 
 
 class WNConvTranspose1d(_WNBase):
@@ -96,12 +98,12 @@ class WNConvTranspose1d(_WNBase):
         self.weight_g = nn.Parameter(ref.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1).clone())
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
 
-    def forward(self, x, act=None, post_act=None):
+    def forward(self, x, act=None, post_act=None, want_raw=False):
         x = _prep(x)
         code, a, b, ls = _act_args(act)
         return conv_ops.conv_transpose1d(x, self._packed(), self._bias(), Cout=self.out_channels,
                                          K=self.kernel_size, stride=self.stride, padding=self.padding, act=code,
-                                         alpha=a, beta=b, logscale=ls, post_act=_post_act(post_act))
+                                         alpha=a, beta=b, logscale=ls, post_act=_post_act(post_act), want_raw=want_raw)
 
 
 def get_activation(activation: Literal["elu", "snake", "none"], antialias=False, channels=None) -> nn.Module:
@@ -135,10 +137,15 @@ class ResidualUnit(nn.Module):
             get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=out_channels),
             WNConv1d(in_channels=out_channels, out_channels=out_channels, kernel_size=1))
 
-    def forward(self, x, post_act=None):
+    def forward(self, x, post_act=None, x_act=None, dual=False):
+        """x_act: layers[0](x) if the producer already stored it (then the k=7 conv stages its input without any activation
+        work); dual: return (post_act(y), y) - the pair the next unit wants"""
         x = _prep(x)
-        h = self.layers[1](x, act=self.layers[0], post_act=self.layers[2])
-        return self.layers[3](h, residual=x, post_act=post_act)
+        if x_act is not None:
+            h = self.layers[1](x_act, post_act=self.layers[2])
+        else:
+            h = self.layers[1](x, act=self.layers[0], post_act=self.layers[2])
+        return self.layers[3](h, residual=x, post_act=post_act, want_raw=dual)
 
 
 class EncoderBlock(nn.Module):
@@ -154,11 +161,13 @@ class EncoderBlock(nn.Module):
             WNConv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=2 * stride, stride=stride,
                      padding=math.ceil(stride / 2)))
 
-    def forward(self, x, post_act=None):
-        x = self.layers[0](x)
-        x = self.layers[1](x)
-        x = self.layers[2](x, post_act=self.layers[3])
-        return self.layers[4](x, post_act=post_act)
+    def forward(self, x, post_act=None, x_act=None, dual=False):
+        """x_act = layers[0].layers[0](x) if the producer stored it; dual: the strided conv returns (post_act(y), y)"""
+        ru = self.layers
+        xa, x = ru[0](x, post_act=ru[1].layers[0], x_act=x_act, dual=True)
+        xa, x = ru[1](x, post_act=ru[2].layers[0], x_act=xa, dual=True)
+        x = ru[2](x, post_act=self.layers[3], x_act=xa)
+        return self.layers[4](x, post_act=post_act, want_raw=dual)
 
 
 class DecoderBlock(nn.Module):
@@ -180,10 +189,13 @@ class DecoderBlock(nn.Module):
             ResidualUnit(in_channels=out_channels, out_channels=out_channels, dilation=9, use_snake=use_snake))
 
     def forward(self, x, pre_activated=False, post_act=None):
-        x = self.layers[1](x, act=None if pre_activated else self.layers[0])
-        x = self.layers[2](x)
-        x = self.layers[3](x)
-        return self.layers[4](x, post_act=post_act)
+        # every unit's output is needed raw (skip path of the next unit) and activated (its first conv): the producers store
+        # both, so no k=7 conv spends VALU time re-activating its input tile once per output-channel tile
+        ru = self.layers
+        xa, x = ru[1](x, act=None if pre_activated else ru[0], post_act=ru[2].layers[0], want_raw=True)
+        xa, x = ru[2](x, post_act=ru[3].layers[0], x_act=xa, dual=True)
+        xa, x = ru[3](x, post_act=ru[4].layers[0], x_act=xa, dual=True)
+        return ru[4](x, post_act=post_act, x_act=xa)
 
 
 class OobleckEncoder(nn.Module):
@@ -205,11 +217,15 @@ class OobleckEncoder(nn.Module):
 
     def forward(self, x):
         n = len(self.layers)
-        x = self.layers[0](x)
-        for i in range(1, n - 2):
-            x = self.layers[i](x, post_act=self.layers[n - 2] if i == n - 3 else None)
         if n == 3:
-            return self.layers[2](x, act=self.layers[1])
+            return self.layers[2](self.layers[0](x), act=self.layers[1])
+        first_act = lambda i: self.layers[i].layers[0].layers[0]      # first activation of encoder block i
+        xa, x = self.layers[0](x, post_act=first_act(1), want_raw=True)
+        for i in range(1, n - 2):
+            if i == n - 3:
+                x = self.layers[i](x, post_act=self.layers[n - 2], x_act=xa)
+            else:
+                xa, x = self.layers[i](x, post_act=first_act(i + 1), x_act=xa, dual=True)
         return self.layers[n - 1](x)
 
 
