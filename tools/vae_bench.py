@@ -41,13 +41,15 @@ if "--layers" in sys.argv:
     def wrap(fn, kind):
         def inner(x, w, bias, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); y = fn(x, w, bias, **kw); e1.record()
+            e0.record(); ret = fn(x, w, bias, **kw); e1.record()
+            y = ret[0] if isinstance(ret, tuple) else ret            # want_raw: (activated, raw) - two stores
             es = x.element_size()
-            byts = (x.numel() + y.numel() + (y.numel() if kw.get("residual") is not None else 0)) * es + w.numel() * 4
+            nout = 2 if isinstance(ret, tuple) else 1
+            byts = (x.numel() + nout * y.numel() + (y.numel() if kw.get("residual") is not None else 0)) * es + w.numel() * 4
             fl = 2.0 * w.numel() * x.shape[0] * (y.shape[2] if kind == "conv" else x.shape[2])
             rec.append(dict(kind=kind, Cin=x.shape[1], Cout=y.shape[1], K=kw["K"], stride=kw.get("stride", 1),
                             dil=kw.get("dilation", 1), Lout=y.shape[2], bytes=byts, flops=fl, ev=(e0, e1)))
-            return y
+            return ret
         return inner
     conv_ops.conv1d, conv_ops.conv_transpose1d = wrap(conv_ops.conv1d, "conv"), wrap(conv_ops.conv_transpose1d, "convT")
     which = "encode" if "--encode" in sys.argv else "decode"
