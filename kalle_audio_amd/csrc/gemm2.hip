@@ -482,6 +482,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     i32x4 fa[8], fb[4];
     unsigned so_cur = 0;
     const bool late = wave >= NW / 2;     // the staggered half
+    if (late) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every issue arbitration by age otherwise
     // prologue of the software pipeline: k-step 0 of tile 0
     ra.template read<0, 8>(0, fa);
     rb.template read<0, 4>(0, fb);
