@@ -207,75 +207,81 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         }
         __syncthreads();
 
-        f32x4 acc[8][QT];
+        // one key block: S^T tiles -> online softmax -> O^T += V^T P^T.  NKT = 16-key tiles processed: 8 for a full block, 2
+        // for a short tail (the 2 keys S = 130 leaves behind would otherwise cost a whole block of MFMAs and exps)
+        auto block = [&](auto nkt_c) {
+            constexpr int NKT = decltype(nkt_c)::value;
+        f32x4 acc[NKT][QT];
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], acc[kt][qt], 0, 0, 0);
+                }
+            }
+            // scale, mask, online softmax (query = lane&15 column; keys on rows 4g+reg of each key tile)
+            float mx[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) mx[qt] = NEG_BIG;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], acc[kt][qt], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sv = acc[kt][qt][r] * SM_SCALE;
+                        sv = (kb[r] == 0.f) ? sv : kb[r];
+                        if (p.causal && k0 + 16 * kt + 4 * g + r > q0 + wave * (16 * QT) + 16 * qt + li + coff)
+                            sv = fminf(sv, NEG_BIG);
+                        acc[kt][qt][r] = sv;
+                        mx[qt] = fmaxf(mx[qt], sv);
+                    }
             }
-        }
-        // scale, mask, online softmax (query = lane&15 column; keys on rows 4g+reg of each key tile)
-        float mx[QT];
+            float alpha[QT];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) mx[qt] = NEG_BIG;
+            for (int qt = 0; qt < QT; ++qt) {
+                const float mn = fmaxf(m[qt], xor16_32_max(mx[qt]));
+                alpha[qt] = __expf(m[qt] - mn);
+                m[qt] = mn;
+                float ps = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
-            const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __expf(acc[kt][qt][r] - mn);
+                        acc[kt][qt][r] = pv;
+                        ps += pv;
+                    }
+                l[qt] = l[qt] * alpha[qt] + ps;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sv = acc[kt][qt][r] * SM_SCALE;
-                    sv = (kb[r] == 0.f) ? sv : kb[r];
-                    if (p.causal && k0 + 16 * kt + 4 * g + r > q0 + wave * (16 * QT) + 16 * qt + li + coff)
-                        sv = fminf(sv, NEG_BIG);
-                    acc[kt][qt][r] = sv;
-                    mx[qt] = fmaxf(mx[qt], sv);
-                }
-        }
-        float alpha[QT];
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float mn = fmaxf(m[qt], xor16_32_max(mx[qt]));
-            alpha[qt] = __expf(m[qt] - mn);
-            m[qt] = mn;
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __expf(acc[kt][qt][r] - mn);
-                    acc[kt][qt][r] = pv;
-                    ps += pv;
-                }
-            l[qt] = l[qt] * alpha[qt] + ps;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha[qt];
-        }
-        // O^T += V^T P^T
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 pb[QT];
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) pb[qt] = pack_pair(acc[2 * ks][qt], acc[2 * ks + 1][qt]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 vf = trfrag(Vs, 32 * ks, 32 * ks + 16, 16 * dt, lane);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[qt], o[dt][qt], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha[qt];
             }
-        }
+            // O^T += V^T P^T
+#pragma unroll
+            for (int ks = 0; ks < NKT / 2; ++ks) {
+                bf16x8 pb[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) pb[qt] = pack_pair(acc[2 * ks][qt], acc[2 * ks + 1][qt]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vf = trfrag(Vs, 32 * ks, 32 * ks + 16, 16 * dt, lane);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[qt], o[dt][qt], 0, 0, 0);
+                }
+            }
+            };
+        if (kval > 32) block(std::integral_constant<int, 8>{});
+        else block(std::integral_constant<int, 2>{});
     }
-
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const float lt = xor16_32_sum(l[qt]);
@@ -430,8 +436,13 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
             }
             __syncthreads();
 
+            // waves whose owner rows are all past the end (the 2-key tail block of S = 130 keeps one wave of eight busy)
+            // and streamed 32-row pairs past the end of a partial block only take part in staging and barriers
+            const int nown_ = KV ? p.Nk : p.Nq;
+            const bool wave_live = o0 + wave * (16 * OT) < nown_;
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
+                if (!wave_live || 32 * pr >= sval) break;
                 f32x4 sa[2][OT], dp[2][OT];  // [streamed tile of the pair][owner tile]
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {

@@ -3,7 +3,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kalle_audio_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-H, Hkv, N, S, D, Dc = 24, 12, 126, 130, 1536, 768
+H, Hkv, N, D, Dc = 24, 12, 126, 1536, 768
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 130
 dev = torch.device("cuda")
 mk = lambda *s: (torch.randn(*s, device=dev) * 0.7).bfloat16()
 qkv, q, kv, dout = mk(B, N, 3 * D), mk(B, N, D), mk(B, S, 2 * Dc), mk(B, N, D)
