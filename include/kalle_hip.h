@@ -292,6 +292,28 @@ int kalle_axpby(const float* x, const float* y, float* out, float a, float b, in
  * y bf16 or fp32 [N], residual fp32 [N] or NULL; K % 8 == 0, K <= 32768 */
 int kalle_gemv_bf16(const void* x, const void* W, int64_t ldw, void* y, int y_dtype, const float* residual, int N, int K,
                     void* stream);
+/* One KV-cached decode step of the whole Llama stack (batch 1, one new position t0), sequenced on the C side so that a
+ * generated frame costs one host call instead of ~150 Python-level launches (model_sigmaVAE.py:122-146 runs
+ * `self.base_model.model(inputs_embeds=...)` over the growing prefix once per frame; with a cache only the new position
+ * is computed).  Per layer: [RMSNorm + fused q|k|v GEMV, k|v written straight into cache row t0] -> causal GQA attention
+ * over rows 0..t0 -> [o_proj GEMV + residual] -> [RMSNorm + up|gate GEMV] -> [SwiGLU + down GEMV + residual].
+ *   layers: HOST array of n_layers descriptors; weights bf16 row-major ([out][in]; wqkv = [q;k;v], wug = [up;gate]),
+ *           norm weights fp32 [D], kv_cache bf16 [cache_rows][2*Hkv*64] holding un-rotated k | v of positions < t0
+ *   x: fp32 [D] input embedding of position t0; out: fp32 [D] residual stream after the last layer (final norm not applied)
+ *   rope_cos / rope_sin: fp32 [>= t0+1][32]; workspace: kalle_llama_decode_ws_bytes(H, Hkv, inner) bytes, 64-byte aligned */
+typedef struct kalle_llama_layer {
+    const float* input_norm;
+    const void* wqkv;
+    const void* wo;
+    const float* post_norm;
+    const void* wug;
+    const void* wdown;
+    void* kv_cache;
+} kalle_llama_layer;
+int kalle_llama_decode_ws_bytes(int H, int Hkv, int inner);
+int kalle_llama_decode_step(const kalle_llama_layer* layers, int n_layers, const float* x, float* out, int H, int Hkv,
+                            int inner, float eps, int t0, int cache_rows, const float* rope_cos, const float* rope_sin,
+                            void* workspace, void* stream);
 /* waveform -> int16 PCM as the inference scripts write it (infer_0723.py:293): out = int16(clamp(x / max|x|, -1, 1) * 32767);
  * peak: one fp32 of device scratch that receives max|x|; x fp32 or bf16 */
 int kalle_peak_normalize_int16(const void* x, int dtype, float* peak, int16_t* out, int64_t n, void* stream);

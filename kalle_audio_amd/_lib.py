@@ -55,6 +55,13 @@ class ConvEpilogue(ctypes.Structure):
                 ("tanh", ctypes.c_int32), ("post_act", Act), ("y_raw", ctypes.c_void_p)]
 
 
+class LlamaLayer(ctypes.Structure):
+    """Mirror of `kalle_llama_layer`."""
+    _fields_ = [("input_norm", ctypes.c_void_p), ("wqkv", ctypes.c_void_p), ("wo", ctypes.c_void_p),
+                ("post_norm", ctypes.c_void_p), ("wug", ctypes.c_void_p), ("wdown", ctypes.c_void_p),
+                ("kv_cache", ctypes.c_void_p)]
+
+
 _CTYPE = {
     "int": ctypes.c_int,
     "int32_t": ctypes.c_int32,

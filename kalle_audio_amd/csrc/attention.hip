@@ -569,6 +569,128 @@ bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t 
     return true;
 }
 
+// ---- single-query attention: decoding against a KV cache (Nq == 1) -------------------------------------------
+// The tiled kernel would spend a 128-query MFMA tile on one query.  Here a workgroup owns one (head, batch): every
+// thread scores one key at a time on the vector ALUs (64-dim dot against the rotated query kept in LDS, rotary applied
+// to the key from its row index), block softmax over the scores in LDS, then P.V with 8 threads per key row (16-byte
+// loads of v) and a shuffle + LDS reduction over the 32 key groups.  Operands are rounded to bf16 at the same points as
+// the tiled kernel (rotated q / k, probabilities) so both paths agree to rounding of the fp32 sums.
+template <int ROT>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);  // [Nk] scores, then probabilities
+    __shared__ float qs[64];
+    __shared__ float red[8];
+    __shared__ float osum[4][64];
+    constexpr int HALF = ROT / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int hk = h / (p.H / p.Hkv);
+    const bf16_t* qsrc = p.q + (int64_t)b * p.ldq + p.q_off + h * 64;
+    const bf16_t* ksrc = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
+    const bf16_t* vsrc = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
+    auto rnd = [](float x) { return bf16_to_f32(f32_to_bf16(x)); };
+
+    if (tid < 64) {
+        float x = bf16_to_f32(qsrc[tid]);
+        if constexpr (ROT > 0) {
+            if (tid < ROT) {
+                const bool lo = tid < HALF;
+                const float partner = bf16_to_f32(qsrc[lo ? tid + HALF : tid - HALF]);
+                const int i = lo ? tid : tid - HALF;
+                const float c = p.cosT[(int64_t)p.qpos * HALF + i], sn = p.sinT[(int64_t)p.qpos * HALF + i];
+                x = rnd(x * c + (lo ? -partner : partner) * sn);
+            }
+        }
+        qs[tid] = x;
+    }
+    __syncthreads();
+
+    float mx = NEG_BIG;
+    for (int j = tid; j < p.Nk; j += 256) {
+        const bf16_t* kp = ksrc + (int64_t)j * p.ldk;
+        float kf[64];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const i32x4 w = reinterpret_cast<const i32x4*>(kp)[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kf[8 * c + 2 * e] = bf16lo((uint32_t)w[e]);
+                kf[8 * c + 2 * e + 1] = bf16hi((uint32_t)w[e]);
+            }
+        }
+        if constexpr (ROT > 0) {
+            const float* cp = p.cosT + (int64_t)j * HALF;
+            const float* sp = p.sinT + (int64_t)j * HALF;
+#pragma unroll
+            for (int i4 = 0; i4 < HALF / 4; ++i4) {
+                const f32x4 c = reinterpret_cast<const f32x4*>(cp)[i4], sn = reinterpret_cast<const f32x4*>(sp)[i4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e;
+                    const float a = kf[i], bb = kf[i + HALF];
+                    kf[i] = rnd(a * c[e] - bb * sn[e]);
+                    kf[i + HALF] = rnd(bb * c[e] + a * sn[e]);
+                }
+            }
+        }
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; d += 2) { a0 += kf[d] * qs[d]; a1 += kf[d + 1] * qs[d + 1]; }
+        float sv = (a0 + a1) * SM_SCALE;
+        if (p.mask && !p.mask[(int64_t)b * p.Nk + j]) sv = NEG_BIG;
+        sc[j] = sv;
+        mx = fmaxf(mx, sv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float ls = 0.f;
+    for (int j = tid; j < p.Nk; j += 256) {
+        const float pv = __expf(sc[j] - m);
+        ls += pv;
+        sc[j] = rnd(pv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+    if (lane == 0) red[4 + wave] = ls;
+    __syncthreads();
+    const float l = red[4] + red[5] + red[6] + red[7];
+
+    const int kg = tid >> 3, d8 = tid & 7;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 4
+    for (int j = kg; j < p.Nk; j += 32) {
+        const i32x4 w = *reinterpret_cast<const i32x4*>(vsrc + (int64_t)j * p.ldv + 8 * d8);
+        const float pj = sc[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] += pj * bf16lo((uint32_t)w[e]);
+            acc[2 * e + 1] += pj * bf16hi((uint32_t)w[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) osum[wave][8 * lane + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float o = (osum[0][tid] + osum[1][tid] + osum[2][tid] + osum[3][tid]) / l;
+        p.out[(int64_t)b * p.ldo + h * 64 + tid] = f32_to_bf16(o);
+        if (tid == 0 && p.lse) p.lse[(int64_t)b * p.H + h] = m + __logf(l);
+    }
+}
+
 }  // namespace
 
 extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
@@ -587,6 +709,14 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
     if (causal && Nk < Nq) return KALLE_ERR_ARG;
     p.qpos = causal ? Nk - Nq : 0;
+    if (Nq == 1 && Nk <= 15360) {   // decoding against a KV cache: scores of all keys fit in LDS (60 KB)
+        const dim3 grid(H, B), block(256);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (rot == 64) KALLE_LAUNCH(attn_decode_kernel<64>, grid, block, (size_t)Nk * 4, st, p);
+        else if (rot == 32) KALLE_LAUNCH(attn_decode_kernel<32>, grid, block, (size_t)Nk * 4, st, p);
+        else KALLE_LAUNCH(attn_decode_kernel<0>, grid, block, (size_t)Nk * 4, st, p);
+        return kalle_check_launch();
+    }
     constexpr int lds = 3 * AT_TILE + 128 * 4;
     static bool attr = false;
     if (!attr) {

@@ -490,7 +490,9 @@ extern "C" int kalle_adam_step(float* param, const float* grad, float* exp_avg, 
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return KALLE_ERR_ARG;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
-    KALLE_LAUNCH(adam_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+    // 30 B / parameter of pure streaming: 16 k workgroups measured 4 % faster than the 2 k grid-stride default
+    const int agrid = (int)std::min<int64_t>(((n >> 2) + 255) / 256 + 1, 16384);
+    KALLE_LAUNCH(adam_kernel, dim3(agrid), dim3(256), 0, static_cast<hipStream_t>(stream), param,
                        grad, exp_avg, exp_avg_sq, static_cast<bf16_t*>(param_bf16), n, lr, beta1, beta2, eps,
                        weight_decay, decoupled, bc1, bc2, grad_scale);
     return kalle_check_launch();

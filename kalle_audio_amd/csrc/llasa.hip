@@ -24,44 +24,134 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x,
 // single-row GEMM for KV-cached decoding (model_sigmaVAE.py:122-146 with a cache): y[n] = sum_k W[n][k] x[k] (+ residual[n]).
 // Pure weight streaming: a wave owns 2 weight rows, its lanes walk K in 16-byte chunks (x staged once per workgroup in
 // LDS), shuffle-reduce, lane 0 writes.  8 rows per 256-thread workgroup -> N/8 workgroups keep every HBM channel busy.
-template <bool YF32>
-__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, int64_t ldw,
-                                                   void* __restrict__ y, const float* __restrict__ res, int N, int K) {
+// The LDS copy of x can be built on the fly so that the decode step needs no separate norm / activation launches:
+//   PRO_RMS:    x fp32 [K] -> bf16(x * (gamma * rsqrt(mean(x^2) + eps)))   (LlamaRMSNorm, same rounding as rms_fwd_kernel)
+//   PRO_SWIGLU: x bf16 [2K] = [up | gate] -> bf16(up * silu(gate))         (LlamaMLP, same rounding as swiglu_fwd_kernel)
+// Rows >= nsplit go to y2 (the k | v part of the fused qkv projection lands directly in its KV-cache row).
+enum { PRO_BF16 = 0, PRO_RMS = 1, PRO_SWIGLU = 2 };
+
+template <bool YF32, int PRO>
+__global__ __launch_bounds__(256) void gemv_kernel(const void* __restrict__ xin, const float* __restrict__ gamma, float eps,
+                                                   const bf16_t* __restrict__ W, int64_t ldw, void* __restrict__ y,
+                                                   void* __restrict__ y2, int nsplit, const float* __restrict__ res,
+                                                   int N, int K, int rpw) {
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(gsm);
-    for (int i = threadIdx.x; i < (K >> 3); i += 256)
-        reinterpret_cast<i32x4*>(xs)[i] = reinterpret_cast<const i32x4*>(x)[i];
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 8 + wave * 2;
-    if (n0 >= N) return;
-    const bool two = n0 + 1 < N;
-    const bf16_t* w0 = W + (int64_t)n0 * ldw;
-    const bf16_t* w1 = W + (int64_t)(two ? n0 + 1 : n0) * ldw;
-    float a0 = 0.f, a1 = 0.f;
-    for (int c = lane; c < (K >> 3); c += 64) {
-        const i32x4 xv = reinterpret_cast<const i32x4*>(xs)[c];
-        const i32x4 u = *reinterpret_cast<const i32x4*>(w0 + 8 * c);
-        const i32x4 v = *reinterpret_cast<const i32x4*>(w1 + 8 * c);
+    // the weight stream does not depend on x: the first PF chunks of both rows are in flight while x is being prepared.
+    // A wave walks `rpw` row pairs (rows ((blockIdx * rpw + p) * 4 + wave) * 2 + {0, 1}); its work is the flat sequence
+    // of (pair, K batch) items, each item's loads issued one item ahead of its FMAs.
+    constexpr int PF = 4;
+    const int nc = K >> 3;
+    const int NB = (nc + 64 * PF - 1) / (64 * PF);
+    const int T = rpw * NB;
+    auto load = [&](int pr, int bb, i32x4* uu, i32x4* vv) {
+        const int n = ((blockIdx.x * rpw + pr) * 4 + wave) * 2;
+        const bf16_t* r0 = W + (int64_t)(n < N ? n : N - 1) * ldw;
+        const bf16_t* r1 = W + (int64_t)(n + 1 < N ? n + 1 : N - 1) * ldw;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x0 = bf16lo((uint32_t)xv[e]), x1 = bf16hi((uint32_t)xv[e]);
-            a0 += bf16lo((uint32_t)u[e]) * x0 + bf16hi((uint32_t)u[e]) * x1;
-            a1 += bf16lo((uint32_t)v[e]) * x0 + bf16hi((uint32_t)v[e]) * x1;
+        for (int j = 0; j < PF; ++j) {
+            const int c = bb * (64 * PF) + lane + 64 * j;
+            const int cc = c < nc ? c : nc - 1;
+            uu[j] = *reinterpret_cast<const i32x4*>(r0 + 8 * cc);
+            vv[j] = *reinterpret_cast<const i32x4*>(r1 + 8 * cc);
+        }
+    };
+    i32x4 u[PF], v[PF];
+    load(0, 0, u, v);
+    if constexpr (PRO == PRO_BF16) {
+        const bf16_t* x = static_cast<const bf16_t*>(xin);
+        for (int i = threadIdx.x; i < (K >> 3); i += 256)
+            reinterpret_cast<i32x4*>(xs)[i] = reinterpret_cast<const i32x4*>(x)[i];
+    } else if constexpr (PRO == PRO_RMS) {
+        __shared__ float red[4];
+        const float* x = static_cast<const float*>(xin);
+        float q = 0.f;
+        for (int i = threadIdx.x; i < (K >> 2); i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+            q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[wave] = q;
+        __syncthreads();
+        const float rr = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+        for (int i = threadIdx.x; i < (K >> 2); i += 256) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i];
+            i32x2 o;
+            o[0] = (int)pack_bf16x2(v[0] * (g[0] * rr), v[1] * (g[1] * rr));
+            o[1] = (int)pack_bf16x2(v[2] * (g[2] * rr), v[3] * (g[3] * rr));
+            reinterpret_cast<i32x2*>(xs)[i] = o;
+        }
+    } else {
+        const bf16_t* h = static_cast<const bf16_t*>(xin);
+        for (int i = threadIdx.x; i < (K >> 3); i += 256) {
+            const i32x4 xv = reinterpret_cast<const i32x4*>(h)[i];
+            const i32x4 gv = reinterpret_cast<const i32x4*>(h + K)[i];
+            i32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = (int)pack_bf16x2(bf16lo((uint32_t)xv[j]) * siluf_(bf16lo((uint32_t)gv[j])),
+                                        bf16hi((uint32_t)xv[j]) * siluf_(bf16hi((uint32_t)gv[j])));
+            reinterpret_cast<i32x4*>(xs)[i] = o;
         }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) {
-        if (res) { a0 += res[n0]; if (two) a1 += res[n0 + 1]; }
-        if constexpr (YF32) {
-            static_cast<float*>(y)[n0] = a0;
-            if (two) static_cast<float*>(y)[n0 + 1] = a1;
-        } else {
-            static_cast<bf16_t*>(y)[n0] = f32_to_bf16(a0);
-            if (two) static_cast<bf16_t*>(y)[n0 + 1] = f32_to_bf16(a1);
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    int pr = 0, bb = 0;
+    for (int t = 0; t < T; ++t) {
+        i32x4 un[PF], vn[PF];
+        const bool more = t + 1 < T;
+        const int npr = bb + 1 == NB ? pr + 1 : pr, nbb = bb + 1 == NB ? 0 : bb + 1;
+        if (more) load(npr, nbb, un, vn);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int c = bb * (64 * PF) + lane + 64 * j;
+            if (c < nc) {
+                const i32x4 xv = reinterpret_cast<const i32x4*>(xs)[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = bf16lo((uint32_t)xv[e]), x1 = bf16hi((uint32_t)xv[e]);
+                    a0 += bf16lo((uint32_t)u[j][e]) * x0 + bf16hi((uint32_t)u[j][e]) * x1;
+                    a1 += bf16lo((uint32_t)v[j][e]) * x0 + bf16hi((uint32_t)v[j][e]) * x1;
+                }
+            }
         }
+        if (bb + 1 == NB) {   // row pair done
+            const int n0 = ((blockIdx.x * rpw + pr) * 4 + wave) * 2;
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            if (lane == 0 && n0 < N) {
+                const bool two = n0 + 1 < N;
+                if (res) { a0 += res[n0]; if (two) a1 += res[n0 + 1]; }
+                // nsplit is even (a multiple of 64 in practice), so a wave's two rows never straddle it
+                void* yo = n0 < nsplit ? y : y2;
+                const int r0 = n0 < nsplit ? n0 : n0 - nsplit;
+                if constexpr (YF32) {
+                    static_cast<float*>(yo)[r0] = a0;
+                    if (two) static_cast<float*>(yo)[r0 + 1] = a1;
+                } else {
+                    static_cast<bf16_t*>(yo)[r0] = f32_to_bf16(a0);
+                    if (two) static_cast<bf16_t*>(yo)[r0 + 1] = f32_to_bf16(a1);
+                }
+            }
+            a0 = a1 = 0.f;
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) { u[j] = un[j]; v[j] = vn[j]; }
+        }
+        pr = npr; bb = nbb;
     }
+}
+
+template <bool YF32, int PRO>
+inline void gemv_launch(const void* x, const float* gamma, float eps, const void* W, int64_t ldw, void* y, void* y2,
+                        int nsplit, const float* res, int N, int K, hipStream_t st) {
+    // several row pairs per wave once there are enough workgroups: the per-workgroup x preparation is amortised
+    const int rpw = N >= 8 * 4 * 512 ? 4 : N >= 8 * 2 * 512 ? 2 : 1;
+    KALLE_LAUNCH((gemv_kernel<YF32, PRO>), dim3((N + 8 * rpw - 1) / (8 * rpw)), dim3(256), (size_t)K * 2, st, x, gamma,
+                 eps, static_cast<const bf16_t*>(W), ldw, y, y2, nsplit, res, N, K, rpw);
 }
 
 // peak normalisation to int16 (infer_0723.py:293: x / max|x| -> clamp(-1, 1) * 32767 -> int16, truncating like .to(int16))
@@ -224,13 +314,49 @@ extern "C" int kalle_gemv_bf16(const void* x, const void* W, int64_t ldw, void* 
     if (!x || !W || !y || N <= 0 || K <= 0 || (K & 7) || (ldw & 7) || K > 32768) return KALLE_ERR_ARG;
     if (y_dtype != KALLE_F32 && y_dtype != KALLE_BF16) return KALLE_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((N + 7) / 8);
-    if (y_dtype == KALLE_F32)
-        KALLE_LAUNCH((gemv_kernel<true>), grid, dim3(256), (size_t)K * 2, st, static_cast<const bf16_t*>(x),
-                     static_cast<const bf16_t*>(W), ldw, y, residual, N, K);
-    else
-        KALLE_LAUNCH((gemv_kernel<false>), grid, dim3(256), (size_t)K * 2, st, static_cast<const bf16_t*>(x),
-                     static_cast<const bf16_t*>(W), ldw, y, residual, N, K);
+    if (y_dtype == KALLE_F32) gemv_launch<true, PRO_BF16>(x, nullptr, 0.f, W, ldw, y, y, N, residual, N, K, st);
+    else gemv_launch<false, PRO_BF16>(x, nullptr, 0.f, W, ldw, y, y, N, residual, N, K, st);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_llama_decode_ws_bytes(int H, int Hkv, int inner) {
+    if (H <= 0 || Hkv <= 0 || inner <= 0) return KALLE_ERR_ARG;
+    const int64_t D = (int64_t)H * 64;
+    // x2 | x3 fp32, lse fp32 (padded), q | ao | hf bf16
+    return (int)(2 * D * 4 + ((H * 4 + 63) & ~63) + D * 2 + D * 2 + 2 * (int64_t)inner * 2);
+}
+
+extern "C" int kalle_llama_decode_step(const kalle_llama_layer* layers, int n_layers, const float* x, float* out, int H,
+                                       int Hkv, int inner, float eps, int t0, int cache_rows, const float* rope_cos,
+                                       const float* rope_sin, void* workspace, void* stream) {
+    if (!layers || n_layers <= 0 || !x || !out || !workspace || !rope_cos || !rope_sin) return KALLE_ERR_ARG;
+    if (H <= 0 || Hkv <= 0 || H % Hkv || inner <= 0 || (inner & 7) || t0 < 0 || t0 >= cache_rows) return KALLE_ERR_ARG;
+    const int D = H * 64, kvw = 2 * Hkv * 64;
+    if (D > 32768 || inner > 32768) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* xa = reinterpret_cast<float*>(ws);               // x2: residual stream after the attention branch
+    float* xb = xa + D;                                     // x3: layer output (input of the next layer)
+    float* lse = xb + D;
+    bf16_t* q = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(lse) + ((H * 4 + 63) & ~63));
+    bf16_t* ao = q + D;
+    bf16_t* hf = ao + D;
+    const float* xin = x;
+    for (int l = 0; l < n_layers; ++l) {
+        const kalle_llama_layer& L = layers[l];
+        if (!L.input_norm || !L.wqkv || !L.wo || !L.post_norm || !L.wug || !L.wdown || !L.kv_cache) return KALLE_ERR_ARG;
+        bf16_t* kv_row = static_cast<bf16_t*>(L.kv_cache) + (int64_t)t0 * kvw;
+        // q -> scratch, k | v -> cache row t0 (un-rotated: the attention kernel rotates by row index)
+        gemv_launch<false, PRO_RMS>(xin, L.input_norm, eps, L.wqkv, D, q, kv_row, D, nullptr, D + kvw, D, st);
+        int rc = kalle_attention_fwd(q, D, 0, L.kv_cache, kvw, 0, L.kv_cache, kvw, Hkv * 64, ao, D, lse, rope_cos, rope_sin,
+                                     64, nullptr, 1, 1, H, Hkv, 1, t0 + 1, stream);
+        if (rc != KALLE_OK) return rc;
+        gemv_launch<true, PRO_BF16>(ao, nullptr, 0.f, L.wo, D, xa, xa, D, xin, D, D, st);
+        gemv_launch<false, PRO_RMS>(xa, L.post_norm, eps, L.wug, D, hf, hf, 2 * inner, nullptr, 2 * inner, D, st);
+        float* xo = l + 1 == n_layers ? out : xb;
+        gemv_launch<true, PRO_SWIGLU>(hf, nullptr, 0.f, L.wdown, inner, xo, xo, D, xa, D, inner, st);
+        xin = xo;
+    }
     return kalle_check_launch();
 }
 

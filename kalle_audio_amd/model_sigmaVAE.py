@@ -289,8 +289,19 @@ class LlamaModel(nn.Module):
         if t0 + n > cache["kv"][0].shape[0]:
             raise ValueError("KV cache too short")
         x = Fn._to_f32(inputs_embeds.contiguous()).view(n, Dm)
-        for layer, kv in zip(self.layers, cache["kv"]):
-            x = LO.layer_fwd_cached(LO.layer_params(layer), x, kv, t0, cache["rope"])
+        if n == 1:
+            # one generated frame: the whole stack is sequenced by kalle_llama_decode_step (one host call)
+            plan = cache.get("plan")
+            if plan is None:
+                ps = [LO.layer_params(layer) for layer in self.layers]
+                plan = cache["plan"] = ops.llama_decode_plan(
+                    [(p.g1, p.wqkv, p.wo, p.g2, p.wug, p.wdown, kv) for p, kv in zip(ps, cache["kv"])],
+                    ps[0].H, ps[0].Hkv, ps[0].wug.shape[0] // 2, x.device)
+                plan["eps"] = ps[0].eps
+            x = ops.llama_decode_step(plan, x.view(Dm), t0, cache["kv"][0].shape[0], cache["rope"], plan["eps"])
+        else:
+            for layer, kv in zip(self.layers, cache["kv"]):
+                x = LO.layer_fwd_cached(LO.layer_params(layer), x, kv, t0, cache["rope"])
         cache["len"] = t0 + n
         return self.norm(x.view(1, n, Dm))
 

@@ -51,12 +51,14 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     ar, ac = _rows2d(a)
     br, bc = _rows2d(b)
-    if (ar == 1 and not a_kmajor and not b_kmajor and out is None and bias is None and gate is None and not glu_mode
+    if (ar == 1 and not a_kmajor and not b_kmajor and out is None and (bias is None or residual is None)
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())) and gate is None and not glu_mode
             and row_mask is None and not accumulate and alpha == 1.0 and M is None and N is None and K is None
             and ac % 8 == 0 and ac <= 32768 and (residual is None or residual.is_contiguous())):
         # single row (decoding against the KV cache): weight-streaming kernel instead of a 128-row MFMA tile
         y = torch.empty((1, br), device=a.device, dtype=out_dtype)
-        check(lib.kalle_gemv_bf16(_p(a), _p(b), b.stride(-2) if b.dim() >= 2 else bc, _p(y), _dt(y), _p(residual), br, ac,
+        check(lib.kalle_gemv_bf16(_p(a), _p(b), b.stride(-2) if b.dim() >= 2 else bc, _p(y), _dt(y),
+                                  _p(residual if residual is not None else bias), br, ac,
                                   _stream()), "kalle_gemv_bf16")
         return y
     if M is None:
@@ -437,3 +439,26 @@ def gauss_kl_bwd(pred, label, mask_a, mask_b, sums, grad_a, grad_b, std):
     check(lib.kalle_gauss_kl_bwd(_p(pred), _p(label), _p(mask_a), _p(mask_b), _p(sums), _p(grad_a), _p(grad_b), _p(dpred),
                                  float(std), rows, d, _stream()), "kalle_gauss_kl_bwd")
     return dpred
+
+
+def llama_decode_plan(layer_tensors, H, Hkv, inner, device):
+    """layer_tensors: per layer (input_norm fp32, wqkv bf16, wo bf16, post_norm fp32, wug bf16, wdown bf16, kv_cache bf16).
+    Returns the host-side descriptor array + workspace of kalle_llama_decode_step (keeps the tensors alive)."""
+    lib = _lib.load()
+    arr = (_lib.LlamaLayer * len(layer_tensors))()
+    for d, ts in zip(arr, layer_tensors):
+        for t in ts:
+            assert t.is_contiguous() and t.device == torch.device(device)
+        d.input_norm, d.wqkv, d.wo, d.post_norm, d.wug, d.wdown, d.kv_cache = (t.data_ptr() for t in ts)
+    ws = torch.empty(lib.kalle_llama_decode_ws_bytes(H, Hkv, inner), device=device, dtype=torch.uint8)
+    return {"layers": arr, "n": len(layer_tensors), "keep": layer_tensors, "ws": ws, "H": H, "Hkv": Hkv, "inner": inner}
+
+
+def llama_decode_step(plan, x, t0, cache_rows, rope, eps):
+    """x fp32 [D] -> fp32 [D]: every decoder layer at position t0 against the KV caches of `plan` (one host call)"""
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    check(lib.kalle_llama_decode_step(ctypes.cast(plan["layers"], ctypes.c_void_p), plan["n"], _p(x), _p(out), plan["H"],
+                                      plan["Hkv"], plan["inner"], eps, t0, cache_rows, _p(rope[0]), _p(rope[1]),
+                                      _p(plan["ws"]), _stream()), "kalle_llama_decode_step")
+    return out

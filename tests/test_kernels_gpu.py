@@ -579,6 +579,50 @@ def test_gemv_single_row(ops, dev, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(16384, 2048), (2048 + 512, 2048), (4098, 264), (1030, 8192)])
+def test_gemv_rows_per_wave_and_bias(ops, dev, N, K):
+    """wide outputs walk several row pairs per wave; a Linear bias rides in the residual slot of the single-row kernel"""
+    x = _mk((1, K), dev, seed=98).bfloat16()
+    w = (_mk((N, K), dev, seed=99) * 0.1).bfloat16()
+    bias = _mk((N,), dev, seed=100)
+    ref = x.float() @ w.float().T
+    assert rel_l2(ops.gemm(x, w, out_dtype=torch.float32), ref) < 1e-5
+    assert rel_l2(ops.gemm(x, w, out_dtype=torch.float32, bias=bias), ref + bias) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nk", [1, 37, 300, 1500])
+@pytest.mark.parametrize("rot,H,Hkv,use_mask", [(64, 4, 2, False), (64, 4, 2, True), (32, 3, 3, False), (0, 2, 1, True)])
+def test_single_query_attention_matches_tiled_kernel(ops, dev, Nk, rot, H, Hkv, use_mask):
+    """Nq == 1 (decoding against a KV cache) runs the vector-ALU single-query kernel: same output and lse as the last
+    query row of the tiled MFMA kernel over the whole causal sequence"""
+    B = 2
+    Dq, Dk = H * 64, Hkv * 64
+    ld = Dq + 2 * Dk
+    qkv = (_mk((B, Nk, ld), dev, seed=120) * 0.8).bfloat16()
+    rope = None
+    if rot:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, device=dev, dtype=torch.float32) / rot))
+        fr = torch.arange(Nk, device=dev, dtype=torch.float32)[:, None] * inv[None, :]
+        rope = (fr.cos().contiguous(), fr.sin().contiguous())
+    mask = None
+    if use_mask:
+        mask = torch.rand(B, Nk, device=dev) > 0.3
+        mask[:, -1] = True
+    kw = dict(ldk=ld, k_off=Dq, ldv=ld, v_off=Dq + Dk, B=B, H=H, Hkv=Hkv, Nk=Nk, rope=rope, key_mask=mask, causal=True)
+    full, lse_full = ops.attention_fwd(qkv, qkv, qkv, ldq=ld, q_off=0, Nq=Nk, **kw)
+    if Nk == 1:   # the tiled reference itself would take the single-query path: check against the value row instead
+        want = qkv[:, :, Dq + Dk:].reshape(B, 1, Hkv, 64).repeat_interleave(H // Hkv, 2).reshape(B, 1, Dq)
+        got, _ = ops.attention_fwd(qkv, qkv, qkv, ldq=ld, q_off=0, Nq=1, **kw)
+        assert rel_l2(got, want) < 1e-6
+        return
+    qlast = qkv[:, -1:, :Dq].contiguous()                               # [B, 1, Dq], ldq = Dq
+    got, lse = ops.attention_fwd(qlast, qkv, qkv, ldq=Dq, q_off=0, Nq=1, **kw)
+    assert rel_l2(got, full[:, -1:]) < 4e-3, rel_l2(got, full[:, -1:])
+    assert (lse[..., 0] - lse_full[..., -1]).abs().max() < 2e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,K,dil,L,act", [(64, 256, 7, 1, 215, 0), (96, 520, 7, 9, 333, 1), (128, 300, 1, 1, 77, 2),
                                                   (40, 256, 3, 3, 1000, 1), (1024, 1024, 7, 3, 100, 1)])
 @pytest.mark.parametrize("stride", [1])

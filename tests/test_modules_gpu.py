@@ -479,6 +479,22 @@ def test_llasa_kv_cache_matches_full_forward(dev, tmp_path):
         got = torch.cat(got, 1)
     assert cache["len"] == 37
     assert rel(got, full) < 1e-2, rel(got, full)
+    # a single new position runs through kalle_llama_decode_step (all layers in one host call, norms / SwiGLU folded
+    # into the GEMV prologues, k | v written straight into the cache row): same result as the per-kernel path
+    from kalle_audio_amd import llama_ops as LO
+    with torch.no_grad():
+        c1, c2 = model.init_cache(64, dev), model.init_cache(64, dev)
+        model.forward_cached(x[:, :20].contiguous(), c1)
+        model.forward_cached(x[:, :20].contiguous(), c2)
+        a = model.forward_cached(x[:, 20:21].contiguous(), c1)
+        assert "plan" in c1
+        xx = x[0, 20:21].float().contiguous()
+        for layer, kv in zip(model.layers, c2["kv"]):
+            xx = LO.layer_fwd_cached(LO.layer_params(layer), xx, kv, 20, c2["rope"])
+        b = model.norm(xx.view(1, 1, -1))
+    assert rel(a, b) < 5e-3, rel(a, b)
+    for k1, k2 in zip(c1["kv"], c2["kv"]):
+        assert rel(k1[20], k2[20]) < 1e-2 and torch.equal(k1[21:], k2[21:])
     ids = torch.randint(0, 300, (9,), device=dev)
     prompt = torch.randn(1, 5, lc["latent_dim"], device=dev)
     noise = torch.randn(12, 1, 1, lc["latent_dim"], device=dev)

@@ -25,7 +25,8 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 with torch.device(dev):
     m = Llasa({"llm_model_name_or_path": d, "latent_dim": 64, "audio_proj_dim": 2048}, Tok(), use_flash_attention=False)
-tr = DataParallelTrainer(m, lr=1e-5, optimizer="AdamW", weight_decay=0.01)
+INFER_ONLY = "--infer-only" in sys.argv      # generation with the KV cache only (for profiling the decode step)
+tr = None if INFER_ONLY else DataParallelTrainer(m, lr=1e-5, optimizer="AdamW", weight_decay=0.01)
 nparam = sum(p.numel() for p in m.parameters())
 ids = torch.randint(0, 128264, (B, L), device=dev)
 lat = torch.randn(B, L, 64, device=dev)
@@ -42,26 +43,27 @@ def step():
     return out
 
 
-for _ in range(2):
+for _ in range(0 if INFER_ONLY else 2):
     out = step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(steps):
+for _ in range(0 if INFER_ONLY else steps):
     out = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 # algorithmic FLOPs: 6 * (non-embedding params) per token + attention 12 * L * D per token per layer (causal: half)
 nonemb = nparam - 128264 * 2048
 fl = (6.0 * nonemb + 16 * 12.0 * L * 2048 * 0.5) * B * L
-print(f"Llasa Llama-3.2-1B-shape train step B={B} L={L}: {dt*1e3:.1f} ms/step, {B*L/dt:.0f} tokens/s, "
-      f"{B*L/12.5/dt:.0f} audio-s/s (12.5 Hz frames), {fl/dt/1e12:.0f} TFLOP/s algorithmic, params {nparam/1e9:.2f} B, "
-      f"loss {out['audio_loss'].item():.3f}")
+if not INFER_ONLY:
+  print(f"Llasa Llama-3.2-1B-shape train step B={B} L={L}: {dt*1e3:.1f} ms/step, {B*L/dt:.0f} tokens/s, "
+        f"{B*L/12.5/dt:.0f} audio-s/s (12.5 Hz frames), {fl/dt/1e12:.0f} TFLOP/s algorithmic, params {nparam/1e9:.2f} B, "
+        f"loss {out['audio_loss'].item():.3f}")
 
-if "--infer" in sys.argv:
+if "--infer" in sys.argv or INFER_ONLY:
     # frame-by-frame generation (Llasa.infer): 64 prompt tokens, 200 frames, KV cache vs the reference's full re-forward
     m.eval()
     pid = torch.randint(0, 128264, (64,), device=dev)
-    for use_cache, nfr in ((True, 200), (False, 200)):
+    for use_cache, nfr in ((True, 200),) if INFER_ONLY else ((True, 200), (False, 200)):
         m.infer(pid, None, end_disp_kl_thres=-1.0, max_length=4, use_cache=use_cache)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
