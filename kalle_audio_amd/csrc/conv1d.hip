@@ -277,14 +277,16 @@ struct ConvPass {        // one pass of the core = one output phase
     int ostride;         // output positions per local position (1, or the stride of a transposed conv)
 };
 
-// COW output channels per wave, 64*LPT positions per wave; WCO of the 4 waves are spread over output channels, the other
-// 4/WCO over positions (tiny-Cout layers: WCO = 1); CI input channels per staged chunk; SPAN = LDS row length.
-template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32>
+// COW output channels per wave, 64*LPT positions per wave; WCO of the NW waves are spread over output channels, the other
+// NW/WCO over positions (tiny-Cout layers: WCO = 1); CI input channels per staged chunk; SPAN = LDS row length.
+// NW = 8 (512 threads) stages x once for 128 output channels: half the x traffic and half the staging instructions per
+// FMA of the 4-wave tiling - what the HBM-side pointwise (k = 1) convs need.
+template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32, int NW = 4>
 __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g, float (*Xs)[SPAN], int b, int co_w,
                                           int lane, int wave, int wave_l) {
     constexpr int LW = 64 * LPT;
     constexpr int NS = SPAN / 64;                     // span slots per lane
-    constexpr int NH = CI / 4;                        // channels of a chunk staged by one wave
+    constexpr int NH = CI / NW;                       // channels of a chunk staged by one wave
     const int nchunks = (p.Cin + CI - 1) / CI;
 
     f32x2 acc[COW][LPT / 2];                          // packed along positions: (l_2j, l_2j+1) share one v_pk_fma_f32
@@ -309,14 +311,14 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
         }
     }
 
-    float stg[NH][NS];                                // wave w stages channels w, w+4, ... of a chunk
+    float stg[NH][NS];                                // wave w stages channels w, w+NW, ... of a chunk
     float s_a[NH], s_b[NH];                           // their activation parameters (scalar loads, issued with the data)
     const cfloat_p aa_c = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.aa));
     const cfloat_p ab_c = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.ab));
     auto gload = [&](int ci0) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const int ci = ci0 + wave + 4 * h;
+            const int ci = ci0 + wave + NW * h;
             if (p.act == 1) {
                 s_a[h] = aa_c[min(ci, p.Cin - 1)];
                 s_b[h] = ab_c[min(ci, p.Cin - 1)];
@@ -334,7 +336,7 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
     auto lstore = [&](int ci0, int buf) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const int c = wave + 4 * h, ci = ci0 + c;
+            const int c = wave + NW * h, ci = ci0 + c;
             float a = p.act_param, inv_b = 0.f;
             if (p.act == 1) {
                 a = s_a[h];
@@ -380,7 +382,7 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
         };
         if (total > 0) {
             wt0 = touch(threadIdx.x);
-            wt1 = touch(threadIdx.x + 256);
+            wt1 = touch(threadIdx.x + 64 * NW);
         }
     };
     auto consume_touch = [&]() { asm volatile("" ::"v"(wt0), "v"(wt1)); };
@@ -472,9 +474,9 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
     }
 }
 
-template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32>
-__global__ __launch_bounds__(256) void conv1d_v2_kernel(ConvParams p) {
-    constexpr int LT = 64 * LPT * (4 / WCO);
+template <int COW, int LPT, int WCO, int CI, int SPAN, bool XF32, bool YF32, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv1d_v2_kernel(ConvParams p) {
+    constexpr int LT = 64 * LPT * (NW / WCO);
     __shared__ float Xs[2 * CI + 1][SPAN];           // two buffers + one pad row for the one-step-ahead prefetch
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -508,8 +510,8 @@ __global__ __launch_bounds__(256) void conv1d_v2_kernel(ConvParams p) {
         g.xtap = g.pspan;
         g.xtap_wrap = 1 - (S - 1) * g.pspan;
     }
-    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane,
-                                                        wave, wave / WCO);
+    conv_core<COW, LPT, WCO, CI, SPAN, XF32, YF32, NW>(p, g, Xs, blockIdx.z, bc * (WCO * COW) + (wave % WCO) * COW, lane,
+                                                            wave, wave / WCO);
 }
 
 // transposed conv: output lo = q*S + r - pad (phase r < S, input position q):
@@ -973,21 +975,28 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     p.co_fast = (int64_t)Cin * ksize * p.CoutP * 4 <= (2 << 20);
     const bool v2_stride = stride == 1 || (dilation == 1 && (stride == 2 || stride == 4 || stride == 8) && ksize <= 32);
     if (v2_stride && p.act != 4 && xf == yf && !getenv("KALLE_CONV_V1")) {
-#define KALLE_CONV_V2(COW, LPT, WCO, CI, SPAN)                                                                         \
+#define KALLE_CONV_V2N(COW, LPT, WCO, CI, SPAN, NW)                                                                    \
     do {                                                                                                                \
-        p.ntile = (Lout + 64 * LPT * (4 / WCO) - 1) / (64 * LPT * (4 / WCO));                                          \
+        p.ntile = (Lout + 64 * LPT * (NW / WCO) - 1) / (64 * LPT * (NW / WCO));                                        \
         p.nco = (Cout + COW * WCO - 1) / (COW * WCO);                                                                   \
         if ((int64_t)p.ntile * p.nco > 0x7fffffff) return KALLE_ERR_ARG;                                                \
         dim3 g(p.ntile * p.nco, 1, B);                                                                                  \
-        if (xf) KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, true, true>), g, dim3(256), 0, st, p);          \
-        else KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, false, false>), g, dim3(256), 0, st, p);           \
+        if (xf)                                                                                                         \
+            KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, true, true, NW>), g, dim3(64 * NW), 0, st, p);      \
+        else                                                                                                            \
+            KALLE_LAUNCH((conv1d_v2_kernel<COW, LPT, WCO, CI, SPAN, false, false, NW>), g, dim3(64 * NW), 0, st, p);    \
         return kalle_check_launch();                                                                                    \
     } while (0)
+#define KALLE_CONV_V2(COW, LPT, WCO, CI, SPAN) KALLE_CONV_V2N(COW, LPT, WCO, CI, SPAN, 4)
         if (stride == 1) {
             const TileChoice tc = pick_tile(Lout, Cout, B, halo, V2_SPAN, 0, 1);
             if (Cout <= 4) {
                 if (halo + 512 <= V2_SPAN) KALLE_CONV_V2(2, 2, 1, 8, 640);
             } else if (tc.cow == 16) {
+                // 8 waves share one staged x tile for 128 output channels (pointwise convs: 32-channel chunks to cover
+                // the HBM latency; measured +15 % at C >= 256, +8 % on the k = 7 convs at C = 256, neutral at C = 128)
+                if (ksize == 1 && Cout > 64) KALLE_CONV_V2N(16, 8, 8, 32, 512, 8);
+                if (ksize != 1 && Cout >= 256 && halo + 512 <= 640) KALLE_CONV_V2N(16, 8, 8, 8, 640, 8);
                 if (ksize == 1) KALLE_CONV_V2(16, 8, 4, 16, 512);   // pointwise conv: longer chunks cover the HBM latency
                 KALLE_CONV_V2(16, 8, 4, 8, 640);
             } else {
@@ -1005,6 +1014,7 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
             if (stride == 8 && (int64_t)Lout * B <= 1024) KALLE_CONV_V2(8, 2, 4, 8, 1088);   // longer: fallback is faster
         }
 #undef KALLE_CONV_V2
+#undef KALLE_CONV_V2N
     }
     if ((L_T - 1) * stride + halo + 1 > MAX_SPAN) return KALLE_ERR_UNSUPPORTED;
     dim3 grid((Lout + L_T - 1) / L_T, (Cout + CO_T - 1) / CO_T, B), block(256);

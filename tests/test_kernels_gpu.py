@@ -360,7 +360,10 @@ def _wn(v, g):
                                                       (24, 24, 7, 1, 3, 1500), (128, 2, 7, 1, 1, 1300),
                                                       (20, 1, 7, 1, 1, 515), (9, 17, 11, 1, 5, 700),
                                                       (24, 40, 8, 4, 1, 2100), (16, 72, 4, 2, 1, 3001),
-                                                      (10, 24, 16, 8, 1, 2500), (8, 8, 6, 2, 1, 130)])
+                                                      (10, 24, 16, 8, 1, 2500), (8, 8, 6, 2, 1, 130),
+                                                      # 8-wave tiles (x staged once per 128 output channels): k = 1, wide k = 7
+                                                      (72, 200, 1, 1, 1, 2500), (136, 136, 1, 1, 1, 2600),
+                                                      (16, 264, 7, 1, 3, 14000)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_conv1d(ops, dev, Cin, Cout, K, stride, dil, L, act):
     from kalle_audio_amd import conv_ops
