@@ -268,9 +268,14 @@ int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const fl
 int kalle_conv_pad_len(int Lout, int ksize, int stride, int padding, int dilation);
 int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding, const kalle_act* act,
                        int phases, void* stream);
+/* workspace (optional, fp32, kalle_conv_cfirst_ws_floats(...) elements; that count is 0 when it would not be used): lets the
+ * launch split the input channels over workgroups too - partial sums land there and a second small kernel applies the
+ * epilogue.  For the bottom of a single-clip encode (1024 -> 2048 stride 8 and 2048 -> 128 at 215 positions, the encoder of
+ * autoencoders.py:116-147 as twj_dataset.py:239 calls it clip by clip). */
+int kalle_conv_cfirst_ws_floats(int B, int Cin, int Cout, int Lout, int ksize);
 int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y, int B, int Cin,
                             int Lp, int Cout, int Lout, int ksize, int stride, int padding, int dilation,
-                            const kalle_conv_epilogue* epi, void* stream);
+                            const kalle_conv_epilogue* epi, float* workspace, void* stream);
 /* the same for a transposed conv (one pass per output phase): x_padded [B][C][Lp] = kalle_conv_pad_act(x, padding =
  * ceil(ksize / stride) - 1), Lp >= kalle_convT_pad_len(Lout, ksize, stride, padding) */
 int kalle_convT_pad_len(int Lout, int ksize, int stride, int padding);

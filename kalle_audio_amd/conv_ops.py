@@ -68,8 +68,10 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
         xp = torch.empty((B, Cin, Lp), device=x.device, dtype=torch.float32)
         check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, lead, ctypes.addressof(ia), stride, _stream()),
               "kalle_conv_pad_act")
+        nws = lib.kalle_conv_cfirst_ws_floats(B, Cin, Cout, Lout, K)    # > 0: input channels split over workgroups too
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws > 0 else None
         check(lib.kalle_conv1d_cfirst_fwd(_p(xp), _p(w_packed), _p(bias), _p(y), B, Cin, Lp, Cout, Lout, K, stride, padding,
-                                          dilation, ctypes.addressof(ep), _stream()), "kalle_conv1d_cfirst_fwd")
+                                          dilation, ctypes.addressof(ep), _p(ws), _stream()), "kalle_conv1d_cfirst_fwd")
         return (y, y_raw) if want_raw else y
     check(lib.kalle_conv1d_fwd(_p(x), _dt(x), _p(w_packed), _p(bias), _p(y), _dt(y), B, Cin, Lin, Cout, Lout, K, stride,
                                padding, dilation, ctypes.addressof(ia), ctypes.addressof(ep), _stream()),

@@ -589,6 +589,8 @@ struct ConvCParams {
     const float* xp; const float* w; const float* bias; const float* res; float* y; float* y_raw;
     int B, Cin, Lp, Cout, CoutP, Lout, K, dil, post;
     int split;           // 1, 2 or 4 waves of a workgroup share one position tile and split the input channels
+    int ks; float* part; // ks > 1: blockIdx.z = b * ks + slice - workgroups split the input channels too; each writes its raw
+                         // partial sums to part[slice][b][co][l] and cfirst_finish_kernel applies bias / residual / epilogue
     // geometry of one pass: conv (nphase 1, taps K, weight row k, x offset k * dil, output l) or one phase r of a transposed
     // conv (taps ceil((K - r) / S), weight row r + m * S, x offset -m, output q * S + r - pad)
     int nphase, npos, xtap, ostride, opad, xlead;
@@ -602,16 +604,16 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
     __shared__ float red[3 * 64 * 64];              // partial accumulators of the input-channel splits (48 KiB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / p.ks, ksl = blockIdx.z - b * p.ks;   // batch item, workgroup-level input-channel slice
     const int S = p.split;                          // waves per position tile
-    const int sp = wave % S;                        // this wave's input-channel slice
+    const int sp = wave % S;                        // this wave's input-channel slice (within the workgroup's)
     const int ph = blockIdx.x % p.nphase;           // output phase (transposed conv), 0 otherwise
     const int l0 = ((blockIdx.x / p.nphase) * (4 / S) + wave / S) * P;   // first (input-side) position of the tile
     const bool live = l0 < p.npos;                  // (whole tile groups stay together: sp-waves of a tile share `live`)
     const int co = blockIdx.y * 256 + 4 * lane;
     const int cw = min(co, p.CoutP - 4);            // clamped weight column (lanes past Cout are never stored)
-    const int cper = (p.Cin + S - 1) / S;
-    const int ci_lo = min(sp * cper, p.Cin), ci_hi = min(ci_lo + cper, p.Cin);
+    const int cper = (p.Cin + S * p.ks - 1) / (S * p.ks);
+    const int ci_lo = min((ksl * S + sp) * cper, p.Cin), ci_hi = min(ci_lo + cper, p.Cin);
     const int kt = p.nphase == 1 ? p.K : (ph < p.K ? (p.K - ph + p.nphase - 1) / p.nphase : 0);   // taps of this pass
     const int wstep = p.nphase;                     // weight k advance per tap (1 for a conv)
     const int T = live ? (ci_hi - ci_lo) * kt : 0;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < P / 2; ++j) acc[c][j] = f32x2{0.f, 0.f};
-    if (p.res && sp == 0 && live) {                 // residual straight into the accumulators (clamped, branch-free)
+    if (p.res && sp == 0 && live && p.ks == 1) {    // residual straight into the accumulators (clamped, branch-free)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float* rp = p.res + ((int64_t)b * p.Cout + min(co + c, p.Cout - 1)) * p.Lout;
@@ -722,6 +724,20 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
         }
     }
     if (!live) return;
+    if (p.ks > 1) {                                 // raw partial sums; the epilogue runs in cfirst_finish_kernel
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cc = co + c;
+            if (cc >= p.Cout) continue;
+            float* pp = p.part + (((int64_t)ksl * p.B + b) * p.Cout + cc) * p.Lout;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int64_t l = (int64_t)(l0 + j) * p.ostride + oo;
+                if (l >= 0 && l < p.Lout) pp[l] = acc[c][j >> 1][j & 1];
+            }
+        }
+        return;
+    }
 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -747,6 +763,31 @@ __global__ __launch_bounds__(256) void conv1d_cfirst_kernel(ConvCParams p) {
             if (p.post & 1) v = tanhf(v);
             yp[l] = v;
         }
+    }
+}
+
+// sums the input-channel slices of a split conv1d_cfirst launch and applies the conv epilogue (same order as above)
+__global__ __launch_bounds__(256) void cfirst_finish_kernel(ConvCParams p) {
+    const int64_t n = (int64_t)p.B * p.Cout * p.Lout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int cc = (int)((i / p.Lout) % p.Cout);
+        float v = p.res ? p.res[i] : 0.f;
+        for (int s = 0; s < p.ks; ++s) v += p.part[(int64_t)s * n + i];
+        v = (v + (p.bias ? p.bias[cc] : 0.f)) * p.out_scale;
+        if (p.post & 2) v += p.y[i];
+        if (p.y_raw) p.y_raw[i] = v;
+        if (p.pact) {
+            float pa = p.pparam, pinv_b = 0.f;
+            if (p.pact == 1) {
+                pa = p.paa[cc];
+                float bb = p.pab[cc];
+                if (p.plogscale) { pa = __expf(pa); bb = __expf(bb); }
+                pinv_b = 1.f / (bb + 1e-9f);
+            }
+            v = act_apply(v, p.pact, pa, pinv_b);
+        }
+        if (p.post & 1) v = tanhf(v);
+        p.y[i] = v;
     }
 }
 
@@ -1044,9 +1085,25 @@ extern "C" int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C,
     return kalle_check_launch();
 }
 
+// workgroup-level input-channel split of the channels-per-lane conv: with few positions AND few output channels even 4
+// waves per tile leave most SIMDs idle while every wave walks Cin * K dependent prefetch steps (the 1024 -> 2048 stride-8
+// and 2048 -> 128 convs at the bottom of a single-clip encode: 112 / 14 position-channel tiles)
+static int cfirst_ksplit(int B, int Cin, int Cout, int Lout, int ksize) {
+    const int64_t waves = (int64_t)((Lout + 15) / 16) * ((Cout + 255) / 256) * B * 4;
+    int ks = 1;
+    while (ks < 16 && waves * ks < 4096 && (int64_t)Cin * ksize / (8 * ks) >= 64) ks *= 2;
+    return ks;
+}
+extern "C" int kalle_conv_cfirst_ws_floats(int B, int Cin, int Cout, int Lout, int ksize) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0) return KALLE_ERR_ARG;
+    const int ks = cfirst_ksplit(B, Cin, Cout, Lout, ksize);
+    const int64_t n = ks > 1 ? (int64_t)ks * B * Cout * Lout : 0;
+    return n > 0x7fffffff ? 0 : (int)n;
+}
+
 extern "C" int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_packed, const float* bias, float* y, int B,
                                        int Cin, int Lp, int Cout, int Lout, int ksize, int stride, int padding,
-                                       int dilation, const kalle_conv_epilogue* epi, void* stream) {
+                                       int dilation, const kalle_conv_epilogue* epi, float* workspace, void* stream) {
     if (!x_padded || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lout <= 0 || ksize <= 0 || dilation <= 0 ||
         stride <= 0 || padding < 0)
         return KALLE_ERR_ARG;
@@ -1058,17 +1115,24 @@ extern "C" int kalle_conv1d_cfirst_fwd(const float* x_padded, const float* w_pac
     // waves without splitting the input channels; aim for >= 2048 (two per SIMD)
     const int64_t waves = (int64_t)((Lout + 15) / 16) * ((Cout + 255) / 256) * B;
     const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
+    const int ks = workspace ? cfirst_ksplit(B, Cin, Cout, Lout, ksize) : 1;   // (the caller sized it with ..._ws_floats)
     // stride > 1: x_padded is de-interleaved into `stride` phase rows (left pad padq * stride): tap k of output l reads
     // phase (k + d) % stride at slot l + (k + d) / stride
     const int padq = (padding + stride - 1) / stride, d = padq * stride - padding;
     const int Lq = stride > 1 ? Lp / stride : 0;
     ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, static_cast<float*>(q.y_raw), B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
-                  dilation, q.post, split, 1, Lout, dilation, 1, 0, stride > 1 ? d * Lq : 0, stride, Lq, stride > 1 ? d : 0,
-                  q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
+                  dilation, q.post, split, ks, workspace, 1, Lout, dilation, 1, 0, stride > 1 ? d * Lq : 0, stride, Lq,
+                  stride > 1 ? d : 0, q.out_scale, q.pact, q.paa, q.pab, q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
     const int tiles_per_wg = 4 / split;
-    dim3 grid(((Lout + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg, (Cout + 255) / 256, B);
+    if ((int64_t)B * ks > 65535) return KALLE_ERR_ARG;
+    dim3 grid(((Lout + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg, (Cout + 255) / 256, B * ks);
     KALLE_LAUNCH(conv1d_cfirst_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (ks > 1) {
+        const int64_t n = (int64_t)B * Cout * Lout;
+        KALLE_LAUNCH(cfirst_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+    }
     return kalle_check_launch();
 }
 
@@ -1091,8 +1155,8 @@ extern "C" int kalle_conv_transpose1d_cfirst_fwd(const float* x_padded, const fl
     const int split = waves >= 2048 ? 1 : (waves >= 1024 ? 2 : 4);
     // x_padded has mmax-1 leading zeros: tap m of input position q reads slot q + (mmax-1) - m
     ConvCParams p{x_padded, w_packed, bias, static_cast<const float*>(q.res), y, static_cast<float*>(q.y_raw), B, Cin, Lp, Cout, (Cout + 7) & ~7, Lout, ksize,
-                  1, q.post, split, stride, nq, -1, stride, padding, mmax - 1, 1, 0, 0, q.out_scale, q.pact, q.paa, q.pab,
-                  q.plogscale, q.pparam};
+                  1, q.post, split, 1, nullptr, stride, nq, -1, stride, padding, mmax - 1, 1, 0, 0, q.out_scale, q.pact, q.paa,
+                  q.pab, q.plogscale, q.pparam};
     if (p.CoutP < 4) return KALLE_ERR_UNSUPPORTED;
     const int tiles_per_wg = 4 / split;
     const int64_t gx = (int64_t)(((nq + 15) / 16 + tiles_per_wg - 1) / tiles_per_wg) * stride;

@@ -627,7 +627,8 @@ def test_single_query_attention_matches_tiled_kernel(ops, dev, Nk, rot, H, Hkv, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,K,dil,L,act", [(64, 256, 7, 1, 215, 0), (96, 520, 7, 9, 333, 1), (128, 300, 1, 1, 77, 2),
-                                                  (40, 256, 3, 3, 1000, 1), (1024, 1024, 7, 3, 100, 1)])
+                                                  (40, 256, 3, 3, 1000, 1), (1024, 1024, 7, 3, 100, 1),
+                                                  (2048, 128, 3, 1, 215, 1)])   # last two: input channels split over workgroups
 @pytest.mark.parametrize("stride", [1])
 def test_conv1d_channels_per_lane_kernel(ops, dev, Cin, Cout, K, dil, L, act, stride, monkeypatch):
     """the few-positions / many-channels kernel (pad+activate pass, then lane = 4 output channels): forced on, against torch"""
@@ -683,7 +684,8 @@ def test_conv_transpose1d_channels_per_lane_kernel(ops, dev, Cin, Cout, stride, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("Cin,Cout,K,stride,pad,L", [(64, 256, 16, 8, 4, 1720), (96, 300, 8, 4, 2, 333), (40, 256, 4, 2, 1, 77),
-                                                     (24, 264, 6, 3, 2, 100), (16, 256, 8, 4, 3, 129)])
+                                                     (24, 264, 6, 3, 2, 100), (16, 256, 8, 4, 3, 129),
+                                                     (512, 520, 16, 8, 4, 800)])      # (workgroup-level channel split)
 def test_strided_conv_channels_per_lane_kernel(ops, dev, Cin, Cout, K, stride, pad, L, monkeypatch):
     """strided convs on the channels-per-lane kernel: the padded copy of x is de-interleaved into `stride` phase rows"""
     from kalle_audio_amd import conv_ops
