@@ -23,6 +23,9 @@ constexpr int AT_STRIDE = 160;             // bytes per LDS row: 64 bf16 + 32 B 
 constexpr int AT_TILE = 128 * AT_STRIDE;   // 20480 B
 constexpr float SM_SCALE = 0.125f;         // 1/sqrt(64)
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float SM_SCALE_LOG2E = SM_SCALE * 1.4426950408889634f;   // exponent of 2 per unit of raw score
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float M_INIT = -2.0e30f;         // running max before the first block: below a fully masked row's NEG_BIG
 
 // stage a [128][64] bf16 tile (rows row0.., `nvalid` valid) into LDS, optionally applying rotary on the first `rot`
 // (32: DiT partial rotary; 64: Llama) dims: out = x cos + rotate_half(x) sin, tables [pos][rot/2].
@@ -127,6 +130,45 @@ __device__ __forceinline__ float xor16_32_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// raw VALU forms: hipcc guards fmaxf / fminf of MFMA results with a canonicalising v_max x, x per operand (signalling-NaN
+// semantics) and only packs some of the fp32 pairs; in the softmax sections those extra instructions cost as much as the
+// exponentials themselves.
+// NB the compiler's hazard recognizer does not look inside inline asm: an MFMA result must not be read by one of these
+// within the MFMA's pass count + 3 cycles.  mfma_results_ready() is the fence between the last MFMA and the first raw use.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mfma_results_ready() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return f32x2{v[0], v[1]}; }
+__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return f32x2{v[2], v[3]}; }
+
 struct AttnParams {
     const bf16_t* q; int64_t ldq; int q_off;
     const bf16_t* k; int64_t ldk; int k_off;
@@ -184,7 +226,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     float m[QT], l[QT];
     f32x4 o[4][QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { m[qt] = NEG_BIG; l[qt] = 0.f; }
+    for (int qt = 0; qt < QT; ++qt) { m[qt] = M_INIT; l[qt] = 0.f; }   // m: running max of the RAW scores
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -212,10 +254,13 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         auto block = [&](auto nkt_c) {
             constexpr int NKT = decltype(nkt_c)::value;
         f32x4 acc[NKT][QT];
+            // S^T = K Q^T on top of the key bias (0 / masked / padding): the MFMA accumulates onto it, so masking costs no
+            // vector instruction.  Scores stay RAW (unscaled) until the exponent.
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+                const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = kb;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
@@ -224,45 +269,48 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                         acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], acc[kt][qt], 0, 0, 0);
                 }
             }
-            // scale, mask, online softmax (query = lane&15 column; keys on rows 4g+reg of each key tile)
-            float mx[QT];
+            mfma_results_ready();
+            // causal: only a block that reaches past this wave's first query compares indices (wave-uniform test)
+            if (p.causal && k0 + 16 * NKT - 1 > q0 + wave * (16 * QT) + coff) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) mx[qt] = NEG_BIG;
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int lim = q0 + wave * (16 * QT) + 16 * qt + li + coff - k0 - 4 * g;   // key offset 16kt + r allowed iff <= lim
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + 16 * kt + 4 * g);
+                    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sv = acc[kt][qt][r] * SM_SCALE;
-                        sv = (kb[r] == 0.f) ? sv : kb[r];
-                        if (p.causal && k0 + 16 * kt + 4 * g + r > q0 + wave * (16 * QT) + 16 * qt + li + coff)
-                            sv = fminf(sv, NEG_BIG);
-                        acc[kt][qt][r] = sv;
-                        mx[qt] = fmaxf(mx[qt], sv);
-                    }
+                        for (int r = 0; r < 4; ++r)
+                            acc[kt][qt][r] = min_raw(acc[kt][qt][r], 16 * kt + r > lim ? NEG_BIG : INFINITY);
+                }
             }
+            // online softmax in the exp2 domain (query = lane&15 column; keys on rows 4g+reg of each key tile):
+            // p = 2^((s - m) * scale * log2 e); the subtraction comes first so that equal huge values (a fully masked row)
+            // give exactly 0
             float alpha[QT];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const float mn = fmaxf(m[qt], xor16_32_max(mx[qt]));
-                alpha[qt] = __expf(m[qt] - mn);
+                float mx = m[qt];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    mx = max3_raw(mx, acc[kt][qt][0], acc[kt][qt][1]);
+                    mx = max3_raw(mx, acc[kt][qt][2], acc[kt][qt][3]);
+                }
+                const float mn = xor16_32_max(mx);
+                alpha[qt] = __builtin_amdgcn_exp2f((m[qt] - mn) * SM_SCALE_LOG2E);
                 m[qt] = mn;
-                float ps = 0.f;
+                const f32x2 nm2 = f32x2{-mn, -mn}, c2 = f32x2{SM_SCALE_LOG2E, SM_SCALE_LOG2E};
+                f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const f32x2 ea = pk_mul(pk_add(lo2(acc[kt][qt]), nm2), c2);
+                    const f32x2 eb = pk_mul(pk_add(hi2(acc[kt][qt]), nm2), c2);
+                    // (consumers of the exponentials are compiler-visible: the trans-unit forwarding hazard is the compiler's)
+                    acc[kt][qt] = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                        __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                    ps4 += acc[kt][qt];
+                }
+                l[qt] = l[qt] * alpha[qt] + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __expf(acc[kt][qt][r] - mn);
-                        acc[kt][qt][r] = pv;
-                        ps += pv;
-                    }
-                l[qt] = l[qt] * alpha[qt] + ps;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha[qt];
+                for (int dt = 0; dt < 4; ++dt) o[dt][qt] *= alpha[qt];      // (feeds the P.V MFMAs as SrcC: no inline asm)
             }
             // O^T += V^T P^T
 #pragma unroll
@@ -296,7 +344,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                 w[1] = (int)pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
                 *reinterpret_cast<i32x2*>(op + 16 * dt) = w;
             }
-            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + qi] = m[qt] + __logf(lt);
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + qi] = m[qt] * SM_SCALE + __logf(lt);
         }
     }
 }
@@ -378,19 +426,21 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
             y2[ot][s] = rowfrag(R2, wave * (16 * OT) + 16 * ot, s, lane);
         }
     // per-owner-column scalars
-    float ca[OT], cb[OT];  // KV: ca = key valid (1/0). !KV: ca = lse[q], cb = delta[q]
+    // KV: ca = score bias of the owner key (0 valid / -inf masked or past the end).  !KV: ca = -lse[q] * log2 e (-inf for
+    // rows past the end), cb = -delta[q] * scale: the addends of the two fused multiply-adds below
+    float ca[OT], cb[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
         const int oi = o0 + wave * (16 * OT) + 16 * ot + li;
         if constexpr (KV) {
             bool ok = oi < p.Nk;
             if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + oi] != 0;
-            ca[ot] = ok ? 1.f : 0.f;
+            ca[ot] = ok ? 0.f : -INFINITY;
             cb[ot] = 0.f;
         } else {
             const bool ok = oi < p.Nq;
-            ca[ot] = ok ? p.lse[((int64_t)b * p.H + hown) * p.Nq + oi] : INFINITY;
-            cb[ot] = ok ? p.delta[((int64_t)b * p.H + hown) * p.Nq + oi] : 0.f;
+            ca[ot] = ok ? -p.lse[((int64_t)b * p.H + hown) * p.Nq + oi] * LOG2E : -INFINITY;
+            cb[ot] = ok ? -p.delta[((int64_t)b * p.H + hown) * p.Nq + oi] * SM_SCALE : 0.f;
         }
     }
 
@@ -422,8 +472,8 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
                 if (tid < 128) {
                     const bool ok = tid < sval;
                     const int64_t idx = ((int64_t)b * p.H + hq) * p.Nq + s0 + tid;
-                    rowa[tid] = ok ? p.lse[idx] : INFINITY;
-                    rowb[tid] = ok ? p.delta[idx] : 0.f;
+                    rowa[tid] = ok ? -p.lse[idx] * LOG2E : -INFINITY;     // P = 2^(s * scale * log2e + rowa)
+                    rowb[tid] = ok ? -p.delta[idx] * SM_SCALE : 0.f;       // dS = P * (dP * scale + rowb)
                 }
             } else {
                 stage_tile<NT>(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
@@ -431,7 +481,7 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
                 if (tid < 128) {
                     bool ok = tid < sval;
                     if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + s0 + tid] != 0;
-                    rowa[tid] = ok ? 1.f : 0.f;
+                    rowa[tid] = ok ? 0.f : -INFINITY;                      // score bias of the streamed key
                 }
             }
             __syncthreads();
@@ -447,9 +497,15 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int rb = 32 * pr + 16 * t;
+                    // rows = streamed index 4g+r, column = owner index.  The validity bias (0 / -inf) of the key side is the
+                    // initial value of the score accumulator: masking costs no vector instruction
+                    const f32x4 ra = *reinterpret_cast<const f32x4*>(rowa + rb + 4 * g);
+                    f32x4 rbv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (KV) rbv = *reinterpret_cast<const f32x4*>(rowb + rb + 4 * g);
 #pragma unroll
                     for (int ot = 0; ot < OT; ++ot) {
-                        sa[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (KV) sa[t][ot] = f32x4{ca[ot], ca[ot], ca[ot], ca[ot]};
+                        else sa[t][ot] = ra;
                         dp[t][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
 #pragma unroll
@@ -462,29 +518,33 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
                             dp[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, y2[ot][s], dp[t][ot], 0, 0, 0);
                         }
                     }
-                    // P and dS in place (rows = streamed index 4g+r, column = owner index)
-                    const f32x4 ra = *reinterpret_cast<const f32x4*>(rowa + rb + 4 * g);
-                    f32x4 rbv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (KV) rbv = *reinterpret_cast<const f32x4*>(rowb + rb + 4 * g);
+                    mfma_results_ready();
+                    // P = 2^(s * scale * log2e - lse * log2e), dS = P * (dP - delta) * scale: two packed fmas, the
+                    // exponentials and a packed multiply per pair of elements
+                    const f32x2 c2 = f32x2{SM_SCALE_LOG2E, SM_SCALE_LOG2E}, sc2 = f32x2{SM_SCALE, SM_SCALE};
+                    // causal: only tiles that touch the masked side of the diagonal compare indices
+                    const int ow = o0 + wave * (16 * OT);
+                    const bool diag = p.causal && (KV ? (ow + 16 * OT - 1 > s0 + rb + coff) : (s0 + rb + 15 > ow + coff));
 #pragma unroll
-                    for (int ot = 0; ot < OT; ++ot)
+                    for (int ot = 0; ot < OT; ++ot) {
+                        f32x2 la, lb, da, db;      // addends: -lse * log2e, -delta * scale
+                        if constexpr (KV) { la = lo2(ra); lb = hi2(ra); da = lo2(rbv); db = hi2(rbv); }
+                        else { la = lb = f32x2{ca[ot], ca[ot]}; da = db = f32x2{cb[ot], cb[ot]}; }
+                        const f32x2 ea = pk_fma(lo2(sa[t][ot]), c2, la), eb = pk_fma(hi2(sa[t][ot]), c2, lb);
+                        f32x4 pv = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                         __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                        if (diag) {
+                            const int oi = ow + 16 * ot + li;                            // owner index
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float pv, dl;
-                            const int si = s0 + rb + 4 * g + r;                          // streamed index
-                            const int oi = o0 + wave * (16 * OT) + 16 * ot + li;         // owner index
-                            if constexpr (KV) {
-                                pv = ca[ot] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ra[r]) : 0.f;
-                                dl = rbv[r];
-                                if (p.causal && oi > si + coff) pv = 0.f;                // key > query
-                            } else {
-                                pv = ra[r] != 0.f ? __expf(sa[t][ot][r] * SM_SCALE - ca[ot]) : 0.f;
-                                dl = cb[ot];
-                                if (p.causal && si > oi + coff) pv = 0.f;
+                            for (int r = 0; r < 4; ++r) {
+                                const int si = s0 + rb + 4 * g + r;                      // streamed index
+                                if (KV ? (oi > si + coff) : (si > oi + coff)) pv[r] = 0.f;   // key > query
                             }
-                            sa[t][ot][r] = pv;
-                            dp[t][ot][r] = pv * (dp[t][ot][r] - dl) * SM_SCALE;
                         }
+                        const f32x2 ta = pk_fma(lo2(dp[t][ot]), sc2, da), tb = pk_fma(hi2(dp[t][ot]), sc2, db);
+                        sa[t][ot] = pv;
+                        dp[t][ot] = pv * f32x4{ta[0], ta[1], tb[0], tb[1]};   // (reads exponentials: compiler-visible multiply)
+                    }
                 }
                 bf16x8 pb[OT], dsb[OT];
 #pragma unroll
