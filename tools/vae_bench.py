@@ -14,13 +14,20 @@ cfg = {"model_type": "autoencoder", "sample_rate": 44100, "sample_size": 441000,
                                                           "strides": [2, 4, 4, 8, 8], "latent_dim": 64, "use_snake": True,
                                                           "final_tanh": False}},
                  "bottleneck": {"type": "vae"}, "latent_dim": 64, "downsampling_ratio": 2048, "io_channels": 2}}
+LAT, RATIO = 64, 2048
+if "--ref-defaults" in sys.argv:
+    # the in-tree defaults of OobleckEncoder / OobleckDecoder (autoencoders.py:117-124, 151-158): 4 levels, latent 32
+    for part, lat in (("encoder", 64), ("decoder", 32)):
+        cfg["model"][part]["config"].update(c_mults=[1, 2, 4, 8], strides=[2, 4, 8, 8], latent_dim=lat)
+    cfg["model"].update(latent_dim=32, downsampling_ratio=512)
+    LAT, RATIO = 32, 512
 dev = torch.device("cuda")
 torch.manual_seed(0)
 with torch.device(dev):
     ae = create_model_from_config(cfg)
 ae.eval().requires_grad_(False)
 dt = torch.bfloat16 if half else torch.float32
-z = torch.randn(B, 64, 215, device=dev).to(dt)
+z = torch.randn(B, LAT, 440320 // RATIO, device=dev).to(dt)
 wav = (torch.rand(B, 2, 440320, device=dev) * 2 - 1).to(dt)
 with torch.no_grad():
     for name, fn in (("decode", lambda: ae.decode(z)), ("encode", lambda: ae.encode(wav))):
