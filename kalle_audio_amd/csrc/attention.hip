@@ -181,7 +181,7 @@ struct AttnParams {
     int causal;          // keys j <= i + (Nk - Nq) only
     int qpos;            // rotary position of query row 0 (Nk - Nq when causal: queries are the LAST Nq positions, KV cache)
     // backward only
-    const bf16_t* dout; const float* delta;
+    const bf16_t* dout; float* delta;
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
 };
 
@@ -350,34 +350,6 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
 }
 
 // ================================================================================================ backward
-// delta[b,h,q] = sum_d dout[b,q,h,d] * out[b,q,h,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                                                         int64_t ldo, float* __restrict__ delta, int B, int H, int Nq) {
-    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;  // (b, q, h)
-    const int sub = threadIdx.x & 7;
-    const int64_t total = (int64_t)B * Nq * H;
-    float s = 0.f;
-    int64_t bq = 0;
-    int h = 0;
-    if (item < total) {
-        bq = item / H;
-        h = (int)(item - bq * H);
-        const int64_t off = bq * ldo + h * 64 + sub * 8;
-        const i32x4 a = *reinterpret_cast<const i32x4*>(out + off);
-        const i32x4 d = *reinterpret_cast<const i32x4*>(dout + off);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            s += bf16lo((uint32_t)a[e]) * bf16lo((uint32_t)d[e]) + bf16hi((uint32_t)a[e]) * bf16hi((uint32_t)d[e]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (item < total && sub == 0) {
-        const int64_t b = bq / Nq, q = bq - b * Nq;
-        delta[(b * H + h) * Nq + q] = s;
-    }
-}
-
 // KV=true : owner = 128 keys of one kv head (grid: key blocks, Hkv, B); streams the queries of every head in the
 //           group; writes dK (un-rotated) and dV.   S[q,key] = Q K^T ; dV^T += dO^T P ; dK^T += Q^T dS
 // KV=false: owner = 128 queries of one head (grid: q blocks, H, B); streams the key blocks; writes dQ (un-rotated).
@@ -413,8 +385,35 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
         const int val = min(128, p.Nq - o0);
         const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hown * 64;
         const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hown * 64;
+        // delta[q] = sum_d dO[q][d] O[q][d] of the owner rows is computed here (4 threads per row: O from global, in flight
+        // with the tile loads; dO from its LDS tile) and stored for the dK/dV kernel, which runs after this one - a
+        // separate pass over dO and O (attn_delta_kernel, 34 us per layer at the bench shape) is gone
+        const int drow = tid >> 2, dq4 = tid & 3;
+        i32x4 o0v = i32x4{0, 0, 0, 0}, o1v = i32x4{0, 0, 0, 0};
+        if (NT == 512 && drow < val) {
+            const bf16_t* op = p.out + ((int64_t)b * p.Nq + o0 + drow) * p.ldo + hown * 64 + 16 * dq4;
+            o0v = *reinterpret_cast<const i32x4*>(op);
+            o1v = *reinterpret_cast<const i32x4*>(op + 8);
+        }
         stage_tile<NT>(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid, p.qpos);
         stage_tile<NT>(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
+        __syncthreads();
+        if (NT == 512) {
+            const i32x4 d0v = *reinterpret_cast<const i32x4*>(R2 + drow * AT_STRIDE + 32 * dq4);
+            const i32x4 d1v = *reinterpret_cast<const i32x4*>(R2 + drow * AT_STRIDE + 32 * dq4 + 16);
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dl += bf16lo((uint32_t)o0v[e]) * bf16lo((uint32_t)d0v[e]) + bf16hi((uint32_t)o0v[e]) * bf16hi((uint32_t)d0v[e]);
+                dl += bf16lo((uint32_t)o1v[e]) * bf16lo((uint32_t)d1v[e]) + bf16hi((uint32_t)o1v[e]) * bf16hi((uint32_t)d1v[e]);
+            }
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            if (dq4 == 0) {
+                rowb[drow] = dl;                       // (rows past the end: O and dO are zero there)
+                if (drow < val) p.delta[((int64_t)b * p.H + hown) * p.Nq + o0 + drow] = dl;
+            }
+        }
     }
     __syncthreads();
     bf16x8 y1[OT][2], y2[OT][2];
@@ -440,7 +439,7 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
         } else {
             const bool ok = oi < p.Nq;
             ca[ot] = ok ? -p.lse[((int64_t)b * p.H + hown) * p.Nq + oi] * LOG2E : -INFINITY;
-            cb[ot] = ok ? -p.delta[((int64_t)b * p.H + hown) * p.Nq + oi] * SM_SCALE : 0.f;
+            cb[ot] = ok ? -rowb[wave * (16 * OT) + 16 * ot + li] * SM_SCALE : 0.f;
         }
     }
 
@@ -802,7 +801,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.q = static_cast<const bf16_t*>(q); p.ldq = ldq; p.q_off = q_off;
     p.k = static_cast<const bf16_t*>(k); p.ldk = ldk; p.k_off = k_off;
     p.v = static_cast<const bf16_t*>(v); p.ldv = ldv; p.v_off = v_off;
-    p.out = nullptr; p.ldo = ldo; p.lse = const_cast<float*>(lse);
+    p.out = static_cast<bf16_t*>(const_cast<void*>(out)); p.ldo = ldo; p.lse = const_cast<float*>(lse);   // (read only here)
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
     if (causal && Nk < Nq) return KALLE_ERR_ARG;
@@ -810,9 +809,6 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 
-    const int64_t items = (int64_t)B * Nq * H;
-    KALLE_LAUNCH(attn_delta_kernel, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st,
-                       static_cast<const bf16_t*>(out), p.dout, ldo, delta, B, H, Nq);
     constexpr int lds = 2 * AT_TILE + 256 * 4;
     static bool attr = false;
     if (!attr) {
@@ -822,7 +818,8 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    KALLE_LAUNCH((attn_bwd_kernel<true, 1>), dim3((Nk + 127) / 128, Hkv, B), dim3(512), lds, st, p);
+    // dQ first: it also produces delta, which the dK/dV kernel streams
     KALLE_LAUNCH((attn_bwd_kernel<false, 1>), dim3((Nq + 127) / 128, H, B), dim3(512), lds, st, p);
+    KALLE_LAUNCH((attn_bwd_kernel<true, 1>), dim3((Nk + 127) / 128, Hkv, B), dim3(512), lds, st, p);
     return kalle_check_launch();
 }
