@@ -156,8 +156,66 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
     float sx[8], sg[8];             // GLU backward: bias-gradient partial sums of this lane's 8 columns
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sg[e] = 0.f; }
+    // The residual (the fp32 stream, updated in place: it aliases C as far as the compiler can tell) is fetched one 16-row
+    // piece AHEAD of the stores: left inside the store loop every one of a wave's 32 load -> add -> store chains exposes a
+    // global-load latency (the pieces are disjoint rows, so reading piece mt+1 before piece mt is stored is safe).
+    const bool pre_res = GLU == 0 && !p.atomic && p.residual != nullptr;
+    f32x4 rnext[4], rcur[4];
+    auto load_res = [&](int mt, f32x4 (&rv)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = row0 + 16 * mt + g + 4 * i, gn = col0 + 4 * li;
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gm < p.M && gn < p.N) rv[i] = *reinterpret_cast<const f32x4*>(p.residual + gemm_crow(p, gm) * p.ldr + gn);
+        }
+    };
+    if (pre_res) load_res(0, rnext);
+    // the bias of a lane's columns is the same for every piece: loaded once (inside the loop each load sits behind the
+    // previous piece's stores, which may alias it for all the compiler knows)
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bx[8], bg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bx[e] = 0.f; bg[e] = 0.f; }
+    if (p.bias) {
+        if constexpr (GLU == 1) {
+            const int j0 = col0 + (lane & 3) * 8;
+            if (j0 < p.glu_inner) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bx[e] = p.bias[j0 + e]; bg[e] = p.bias[p.glu_inner + j0 + e]; }
+            }
+        } else if constexpr (GLU == 0) {
+            if (!p.atomic && col0 + 4 * li < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4 * li);
+        }
+    }
+    // fused SwiGLU backward: the saved pre-activations h (x | gate) of a piece, fetched one piece ahead like the residual
+    i32x4 hnext[2][2], hcur[2][2];
+    auto load_h = [&](int mt, i32x4 (&hv)[2][2]) {
+        const int c8 = (lane & 7) * 8, j0 = col0 + c8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int gm = row0 + 16 * mt + (lane >> 3) + 8 * half;
+            hv[half][0] = i32x4{0, 0, 0, 0};
+            hv[half][1] = i32x4{0, 0, 0, 0};
+            if (gm < p.M && j0 < p.glu_inner) {
+                const bf16_t* hp = static_cast<const bf16_t*>(p.glu_aux) + (int64_t)gm * 2 * p.glu_inner;
+                hv[half][0] = *reinterpret_cast<const i32x4*>(hp + j0);
+                hv[half][1] = *reinterpret_cast<const i32x4*>(hp + p.glu_inner + j0);
+            }
+        }
+    };
+    if constexpr (GLU == 2) load_h(0, hnext);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
+        if constexpr (GLU == 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) { hcur[half][0] = hnext[half][0]; hcur[half][1] = hnext[half][1]; }
+            if (mt + 1 < TM) load_h(mt + 1, hnext);
+        }
+        if (pre_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
+            if (mt + 1 < TM) load_res(mt + 1, rnext);
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -172,10 +230,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 float xv[8], gv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xv[e] = patch[r * PLD + c8 + e]; gv[e] = patch[r * PLD + 32 + c8 + e]; }
-                if (p.bias) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { xv[e] += p.bias[j0 + e]; gv[e] += p.bias[p.glu_inner + j0 + e]; }
-                }
+                for (int e = 0; e < 8; ++e) { xv[e] += bx[e]; gv[e] += bg[e]; }
                 i32x4 hx, hg, av;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -199,9 +255,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int r = (lane >> 3) + 8 * half;
                 const int gm = rbase + r;
                 if (gm < p.M && j0 < p.glu_inner) {
-                    const bf16_t* hp = static_cast<const bf16_t*>(p.glu_aux) + (int64_t)gm * 2 * p.glu_inner;
-                    const i32x4 xv = *reinterpret_cast<const i32x4*>(hp + j0);
-                    const i32x4 gv = *reinterpret_cast<const i32x4*>(hp + p.glu_inner + j0);
+                    const i32x4 xv = hcur[half][0], gv = hcur[half][1];
                     i32x4 ox, og;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -245,7 +299,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + r * PLD + 4 * li);
                 float v[4] = {pv[0], pv[1], pv[2], pv[3]};
                 const int64_t crow = gemm_crow(p, gm);
-                gemm_epilogue4(p, gm, gn, crow, v);
+                gemm_epilogue4(p, gm, gn, crow, v, false, &bias4);
+                if (pre_res) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rcur[i][j];
+                }
                 if constexpr (C_F32) {
                     float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
                     if (p.accumulate) {

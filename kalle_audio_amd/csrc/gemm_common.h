@@ -51,11 +51,12 @@ __device__ __forceinline__ int64_t gemm_crow(const GemmParams& p, int gm) {
 }
 
 // v[0..3] = accumulators of row gm, columns gn..gn+3 ; applies alpha, bias, adaLN gate, row mask, residual
-__device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int gm, int gn, int64_t crow, float (&v)[4]) {
+__device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int gm, int gn, int64_t crow, float (&v)[4],
+                                               bool with_residual = true, const f32x4* bias_pre = nullptr) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-    if (p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + gn);
+    if (p.bias) {   // bias_pre: the caller already holds this lane's 4 bias values
+        const f32x4 b = bias_pre ? *bias_pre : *reinterpret_cast<const f32x4*>(p.bias + gn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += b[j];
     }
@@ -68,7 +69,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmParams& p, int gm, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = 0.f;
     }
-    if (p.residual) {
+    if (with_residual && p.residual) {
         const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + crow * p.ldr + gn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
