@@ -31,61 +31,59 @@ constexpr float M_INIT = -2.0e30f;         // running max before the first block
 // (32: DiT partial rotary; 64: Llama) dims: out = x cos + rotate_half(x) sin, tables [pos][rot/2].
 // Split in two so that a kernel can put the global loads of several tiles in flight together (one HBM latency instead
 // of one per tile) and do the rotary + LDS writes afterwards.
+// A thread owns ONE row and TWO 8-element chunks of it: the two partners of a rotary pair (chunk j and j + rot/16), so the
+// rotation needs no second load of the partner and one fetch of the cos / sin row per pair (a quarter of the table traffic
+// and half the data traffic of one-chunk-per-thread staging); chunks outside the rotary dims are plain adjacent pairs.
 template <int NT>
 struct TileRegs {
-    i32x4 v[1024 / NT], pv[1024 / NT];
+    static_assert(NT == 512, "128 rows x 4 chunk pairs");
+    i32x4 v[2];
 };
+__device__ __forceinline__ void tile_chunks(int rot, int j, int& ca, int& cb) {
+    const int hc = rot >> 4;                            // 8-element chunks per rotary half: 0, 2 (DiT) or 4 (Llama)
+    if (j < hc) { ca = j; cb = j + hc; }                // a rotary pair
+    else if (hc == 2) { ca = 2 * j; cb = 2 * j + 1; }   // rot 32: j = 2, 3 -> chunks (4, 5), (6, 7) pass through
+    else { ca = 2 * j; cb = 2 * j + 1; }                // rot 0
+}
 template <int NT>
 __device__ __forceinline__ void tile_load(TileRegs<NT>& t, const bf16_t* src, int64_t ld, int row0, int nvalid, int rot,
                                           int tid) {
-#pragma unroll
-    for (int i = 0; i < 1024 / NT; ++i) {
-        const int id = tid + NT * i;
-        const int row = id >> 3, c = id & 7;
-        t.v[i] = i32x4{0, 0, 0, 0};
-        t.pv[i] = i32x4{0, 0, 0, 0};
-        if (row < nvalid) {
-            const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
-            t.v[i] = *reinterpret_cast<const i32x4*>(rp + 8 * c);
-            const int hc = rot >> 4;                    // 8-element chunks per rotary half (2 or 4)
-            if (rot && c < 2 * hc) t.pv[i] = *reinterpret_cast<const i32x4*>(rp + 8 * (c ^ hc));
-        }
+    const int row = tid >> 2;
+    int ca, cb;
+    tile_chunks(rot, tid & 3, ca, cb);
+    t.v[0] = i32x4{0, 0, 0, 0};
+    t.v[1] = i32x4{0, 0, 0, 0};
+    if (row < nvalid) {
+        const bf16_t* rp = src + (int64_t)(row0 + row) * ld;
+        t.v[0] = *reinterpret_cast<const i32x4*>(rp + 8 * ca);
+        t.v[1] = *reinterpret_cast<const i32x4*>(rp + 8 * cb);
     }
 }
 template <int NT>
 __device__ __forceinline__ void tile_store(char* lds, const TileRegs<NT>& t, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
                                            int tid, int pos_off = 0) {
+    const int row = tid >> 2, j = tid & 3;
+    int ca, cb;
+    tile_chunks(rot, j, ca, cb);
+    i32x4 va = t.v[0], vb = t.v[1];
+    if (row < nvalid && j < (rot >> 4)) {               // out_a = a cos - b sin, out_b = b cos + a sin (rotate_half)
+        const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+        const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
-    for (int i = 0; i < 1024 / NT; ++i) {
-        const int id = tid + NT * i;
-        const int row = id >> 3, c = id & 7;
-        i32x4 v = t.v[i];
-        if (row < nvalid) {
-            const int hc = rot >> 4;
-            if (rot && c < 2 * hc) {
-                const i32x4 pv = t.pv[i];
-                const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
-                const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + (c & (hc - 1)) * 8;
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                const float sg = (c < hc) ? -1.f : 1.f;  // rotate_half: first half gets -x2, second half +x1
-                float o[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t0 = bf16lo((uint32_t)v[e]), t1 = bf16hi((uint32_t)v[e]);
-                    const float p0 = bf16lo((uint32_t)pv[e]), p1 = bf16hi((uint32_t)pv[e]);
-                    const float cc0 = e < 2 ? c0[2 * e] : c1[2 * e - 4], cc1 = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
-                    const float ss0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], ss1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
-                    o[2 * e] = t0 * cc0 + sg * p0 * ss0;
-                    o[2 * e + 1] = t1 * cc1 + sg * p1 * ss1;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (int)pack_bf16x2(o[2 * e], o[2 * e + 1]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf16lo((uint32_t)va[e]), a1 = bf16hi((uint32_t)va[e]);
+            const float b0 = bf16lo((uint32_t)vb[e]), b1 = bf16hi((uint32_t)vb[e]);
+            const float cc0 = e < 2 ? c0[2 * e] : c1[2 * e - 4], cc1 = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
+            const float ss0 = e < 2 ? s0[2 * e] : s1[2 * e - 4], ss1 = e < 2 ? s0[2 * e + 1] : s1[2 * e - 3];
+            va[e] = (int)pack_bf16x2(a0 * cc0 - b0 * ss0, a1 * cc1 - b1 * ss1);
+            vb[e] = (int)pack_bf16x2(b0 * cc0 + a0 * ss0, b1 * cc1 + a1 * ss1);
         }
-        *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * c) = v;
     }
+    *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * ca) = va;
+    *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * cb) = vb;
 }
 template <int NT>
 __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
