@@ -374,11 +374,29 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
     const bf16_t* kbase = p.k + (int64_t)b * p.Nk * p.ldk + p.k_off + hk * 64;
     const bf16_t* vbase = p.v + (int64_t)b * p.Nk * p.ldv + p.v_off + hk * 64;
 
+    // The first streamed block (first query block of the group's first head / first key block) is fetched together with the
+    // owner tiles - one global-load latency per workgroup instead of two.  With causal masking the dK/dV kernel starts at the
+    // first query block that can see its keys.
+    const int nstream = KV ? p.Nq : p.Nk;
+    const int coff = p.Nk - p.Nq;
+    int sfirst = 0;
+    if (KV && p.causal) sfirst = ((max(o0 - coff - 127, 0) + 127) / 128) * 128;
+    const bool has_first = sfirst < nstream;
+    const int sval0 = min(128, nstream - sfirst);
+    TileRegs<NT> f1, f2;
     // ---- owner fragments -> registers ----
     if constexpr (KV) {
         const int val = min(128, p.Nk - o0);
-        stage_tile<NT>(R1, kbase, p.ldk, o0, val, p.cosT, p.sinT, p.rot, tid);
-        stage_tile<NT>(R2, vbase, p.ldv, o0, val, nullptr, nullptr, 0, tid);
+        TileRegs<NT> t1, t2;
+        tile_load<NT>(t1, kbase, p.ldk, o0, val, p.rot, tid);
+        tile_load<NT>(t2, vbase, p.ldv, o0, val, 0, tid);
+        if (has_first) {
+            const int hq0 = hk * group;
+            tile_load<NT>(f1, p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hq0 * 64, p.ldq, sfirst, sval0, p.rot, tid);
+            tile_load<NT>(f2, p.dout + (int64_t)b * p.Nq * p.ldo + hq0 * 64, p.ldo, sfirst, sval0, 0, tid);
+        }
+        tile_store<NT>(R1, t1, o0, val, p.cosT, p.sinT, p.rot, tid);
+        tile_store<NT>(R2, t2, o0, val, nullptr, nullptr, 0, tid);
     } else {
         const int val = min(128, p.Nq - o0);
         const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hown * 64;
@@ -393,8 +411,15 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
             o0v = *reinterpret_cast<const i32x4*>(op);
             o1v = *reinterpret_cast<const i32x4*>(op + 8);
         }
-        stage_tile<NT>(R1, qb, p.ldq, o0, val, p.cosT, p.sinT, p.rot, tid, p.qpos);
-        stage_tile<NT>(R2, dob, p.ldo, o0, val, nullptr, nullptr, 0, tid);
+        TileRegs<NT> t1, t2;
+        tile_load<NT>(t1, qb, p.ldq, o0, val, p.rot, tid);
+        tile_load<NT>(t2, dob, p.ldo, o0, val, 0, tid);
+        if (has_first) {
+            tile_load<NT>(f1, kbase, p.ldk, sfirst, sval0, p.rot, tid);
+            tile_load<NT>(f2, vbase, p.ldv, sfirst, sval0, 0, tid);
+        }
+        tile_store<NT>(R1, t1, o0, val, p.cosT, p.sinT, p.rot, tid, p.qpos);
+        tile_store<NT>(R2, t2, o0, val, nullptr, nullptr, 0, tid);
         __syncthreads();
         if (NT == 512) {
             const i32x4 d0v = *reinterpret_cast<const i32x4*>(R2 + drow * AT_STRIDE + 32 * dq4);
@@ -450,22 +475,30 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
             g2[dt][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-    const int nstream = KV ? p.Nq : p.Nk;
     const int nheads = KV ? group : 1;
-    const int coff = p.Nk - p.Nq;
+    // the prefetched first block goes to LDS as soon as the owner fragments have been read out of it: its registers are dead
+    // before the loop (kept alive by a flag inside the loop they would cost 16 VGPRs in every iteration)
+    if (has_first) {
+        __syncthreads();
+        tile_store<NT>(R1, f1, sfirst, sval0, p.cosT, p.sinT, p.rot, tid, KV ? p.qpos : 0);
+        tile_store<NT>(R2, f2, sfirst, sval0, nullptr, nullptr, 0, tid);
+    }
+    bool first = has_first;                 // (the first block the loop reaches is block `sfirst` of head 0)
     for (int hh = 0; hh < nheads; ++hh) {
         const int hq = KV ? hk * group + hh : hown;
         for (int s0 = 0; s0 < nstream; s0 += 128) {
             if (p.causal) {   // whole streamed block on the masked side of the diagonal (uniform per workgroup)
                 if (KV ? (s0 + 127 + coff < o0) : (s0 > o0 + 127 + coff)) continue;
             }
-            __syncthreads();  // previous tile fully consumed (also guards the owner-fragment reads)
+            if (!first) __syncthreads();  // previous tile fully consumed
             const int sval = min(128, nstream - s0);
             if constexpr (KV) {
                 const bf16_t* qb = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + hq * 64;
                 const bf16_t* dob = p.dout + (int64_t)b * p.Nq * p.ldo + hq * 64;
-                stage_tile<NT>(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid, p.qpos);
-                stage_tile<NT>(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
+                if (!first) {
+                    stage_tile<NT>(R1, qb, p.ldq, s0, sval, p.cosT, p.sinT, p.rot, tid, p.qpos);
+                    stage_tile<NT>(R2, dob, p.ldo, s0, sval, nullptr, nullptr, 0, tid);
+                }
                 if (tid < 128) {
                     const bool ok = tid < sval;
                     const int64_t idx = ((int64_t)b * p.H + hq) * p.Nq + s0 + tid;
@@ -473,14 +506,17 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
                     rowb[tid] = ok ? -p.delta[idx] * SM_SCALE : 0.f;       // dS = P * (dP * scale + rowb)
                 }
             } else {
-                stage_tile<NT>(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
-                stage_tile<NT>(R2, vbase, p.ldv, s0, sval, nullptr, nullptr, 0, tid);
+                if (!first) {
+                    stage_tile<NT>(R1, kbase, p.ldk, s0, sval, p.cosT, p.sinT, p.rot, tid);
+                    stage_tile<NT>(R2, vbase, p.ldv, s0, sval, nullptr, nullptr, 0, tid);
+                }
                 if (tid < 128) {
                     bool ok = tid < sval;
                     if (ok && p.mask) ok = p.mask[(int64_t)b * p.Nk + s0 + tid] != 0;
                     rowa[tid] = ok ? 0.f : -INFINITY;                      // score bias of the streamed key
                 }
             }
+            first = false;
             __syncthreads();
 
             // waves whose owner rows are all past the end (the 2-key tail block of S = 130 keeps one wave of eight busy)
