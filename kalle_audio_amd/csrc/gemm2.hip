@@ -678,6 +678,8 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
             if (t < best * 0.98) { best = t; best_bn = bn; best_s = s; }
         }
     }
+    static const int s_env = getenv("KALLE_GEMM_SPLITS") ? atoi(getenv("KALLE_GEMM_SPLITS")) : 0;
+    if (s_env > 0 && can_split && nk / s_env >= 8) best_s = s_env;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + best_bn - 1) / best_bn;
     p.tile_n = best_bn;
