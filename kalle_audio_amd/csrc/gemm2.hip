@@ -13,6 +13,7 @@
 // Split-K (wgrad: the output is weight-shaped, the contraction runs over all tokens) turns the grid into
 // tiles x splits with fp32 atomics into a zeroed C - this is what fills 256 CUs when the output has < 256 tiles.
 // Requirements: K % 64 == 0 (otherwise the dispatcher uses the 128x128 kernel of gemm.hip).
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -502,12 +503,24 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    int tm, tn;
-    gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
     const int nk_all = p.K / BK2;
-    const int kt0 = blockIdx.y * p.ktiles_per_split;
-    const int nk = min(p.ktiles_per_split, nk_all - kt0);
+    int tm, tn, kt0, nk;
+    if (p.mix_na >= 0) {
+        // mixed split-K: 1-D grid; blocks [0, na * sa) = tiles [0, na) x sa slices (tile fastest), then the other tiles x (sa + 1)
+        const int ntiles = p.tiles_m * p.tiles_n, na = p.mix_na, sa = p.mix_sa;
+        int bid = blockIdx.x, tile, slice, per;
+        if (bid < na * sa) { tile = bid % na; slice = bid / na; per = (nk_all + sa - 1) / sa; }
+        else { bid -= na * sa; const int nb = ntiles - na; tile = na + bid % nb; slice = bid / nb; per = (nk_all + sa) / (sa + 1); }
+        gemm_tile_coords(tile, ntiles, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        kt0 = slice * per;
+        nk = min(per, nk_all - kt0);
+        if (nk <= 0) return;                 // (uniform per workgroup)
+    } else {
+        gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        kt0 = blockIdx.y * p.ktiles_per_split;
+        nk = min(p.ktiles_per_split, nk_all - kt0);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[TM][4];
 #pragma unroll
@@ -600,6 +613,10 @@ int launch3(const GemmParams& p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
+    if (p.mix_na >= 0) {
+        const int ntiles = p.tiles_m * p.tiles_n;
+        grid = dim3(p.mix_na * p.mix_sa + (ntiles - p.mix_na) * (p.mix_sa + 1), 1);
+    }
     KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32, GLU>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
@@ -633,6 +650,8 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st) {
+    p.mix_na = -1;
+    p.mix_sa = 0;
     if (p.K % BK2) return KALLE_ERR_UNSUPPORTED;
     if (a_km && !b_km) return KALLE_ERR_UNSUPPORTED;
     if (a_km && !f32) return KALLE_ERR_UNSUPPORTED;
@@ -676,6 +695,77 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
             const double eff = (double)blocks / (((blocks + 255) / 256) * 256.0);
             const double t = flops / (rate * eff) + (s > 1 ? (double)s * p.M * p.N * 4.0 / 2.0e12 : 0.0);
             if (t < best * 0.98) { best = t; best_bn = bn; best_s = s; }
+        }
+    }
+    // Weight gradients on the 256 x 256 kernel: mixed split-K.  `na` tiles get `sa` K slices, the others sa + 1, the longer
+    // slices are dispatched first: the last round of workgroups then consists of short slices instead of leaving most CUs idle
+    // (288 tiles x 3 slices = 3.4 rounds -> 4 with uniform splitting).  The plan comes from replaying the dispatch on 256 CUs
+    // (time of a slice = 10 us + 1.6 us per K-tile, atomics at 2 TB/s - fitted to tools/wgrad_sweep.py) and is cached per shape.
+    if (can_split && best_bn == 256 && !tile_env && !getenv("KALLE_GEMM_NOMIX")) {
+        struct Plan { int M, N, K, sa, na; };
+        static thread_local Plan cache[32];
+        static thread_local int ncache = 0;
+        const Plan* hit = nullptr;
+        int sa_sel = 0, na_sel = -1;
+        for (int i = 0; i < ncache; ++i)
+            if (cache[i].M == p.M && cache[i].N == p.N && cache[i].K == p.K) hit = &cache[i];
+        if (!hit) {
+            const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+            auto replay = [&](int sa, int na) {        // makespan (us) of the dispatch order on 256 CUs + atomic traffic
+                double cu[256] = {0.0};
+                auto run = [&](int tiles, int slices) {
+                    if (tiles <= 0 || slices <= 0) return;
+                    const int per = (nk + slices - 1) / slices;
+                    for (int sl = 0; sl < slices; ++sl) {
+                        const int k = nk - sl * per < per ? nk - sl * per : per;
+                        if (k <= 0) break;
+                        for (int t = 0; t < tiles; ++t) {
+                            int m = 0;
+                            for (int c = 1; c < 256; ++c) if (cu[c] < cu[m]) m = c;
+                            cu[m] += 10.0 + 1.6 * k;
+                        }
+                    }
+                };
+                run(na, sa);
+                run(ntiles - na, sa + 1);
+                double mk = 0.0;
+                for (int c = 0; c < 256; ++c) mk = cu[c] > mk ? cu[c] : mk;
+                const double savg = ((double)na * sa + (double)(ntiles - na) * (sa + 1)) / ntiles;
+                return mk + (savg > 1.0 ? savg * p.M * p.N * 4.0 / 2.0e12 * 1e6 : 0.0);
+            };
+            Plan best_plan{p.M, p.N, p.K, 0, -1};
+            double t_uniform = 1e30, t_best = 1e30;
+            const int step = ntiles > 64 ? 16 : 4;
+            for (int sa = 0; sa <= 7; ++sa) {
+                if (nk / (sa + 1) < 8) break;
+                for (int na = 0; na <= (sa == 0 ? 0 : ntiles); na += step) {
+                    const double t = replay(sa, na);
+                    if (na == 0 && t < t_uniform) t_uniform = t;       // (na = 0: uniform sa + 1 slices)
+                    if (t < t_best) { t_best = t; best_plan.sa = sa; best_plan.na = na; }
+                }
+            }
+            for (int s = 9; s <= 16 && nk / s >= 8; ++s) {                 // uniform plans beyond the mixed range
+                const double t = replay(s - 1, 0);
+                if (t < t_uniform) t_uniform = t;
+            }
+            if (!(best_plan.na > 0 && t_best < 0.97 * t_uniform)) best_plan.na = -1;   // not worth leaving the uniform plan
+            if (ncache < 32) cache[ncache++] = best_plan;
+            sa_sel = best_plan.sa;
+            na_sel = best_plan.na;
+        } else {
+            sa_sel = hit->sa;
+            na_sel = hit->na;
+        }
+        if (getenv("KALLE_GEMM_DEBUG")) fprintf(stderr, "[kalle gemm] %d x %d x %d: mixed split sa=%d na=%d (hit=%d)\n", p.M, p.N, p.K, sa_sel, na_sel, hit != nullptr);
+        if (na_sel > 0) { p.mix_na = na_sel; p.mix_sa = sa_sel; best_s = sa_sel + 1; }
+    }
+    if (const char* e = getenv("KALLE_GEMM_MIX")) {      // "sa,na": experiment override
+        int sa = 0, na = 0;
+        if (can_split && sscanf(e, "%d,%d", &sa, &na) == 2 && sa >= 1 && best_bn == 256 && nk / (sa + 1) >= 8) {
+            const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+            p.mix_sa = sa;
+            p.mix_na = na < ntiles ? na : ntiles;
+            best_s = sa + 1;                             // (>1: atomic epilogue + cleared C below)
         }
     }
     static const int s_env = getenv("KALLE_GEMM_SPLITS") ? atoi(getenv("KALLE_GEMM_SPLITS")) : 0;

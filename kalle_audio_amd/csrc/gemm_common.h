@@ -22,6 +22,9 @@ struct GemmParams {
     const uint8_t* row_mask;
     // gemm2 only
     int tiles_m, splits, ktiles_per_split, atomic, group_m, tile_n;
+    // mixed split-K (gemm3 weight gradients): the first mix_na tiles are cut into mix_sa K slices, the rest into mix_sa + 1;
+    // 1-D grid, the longer slices first, so that the last round of workgroups is made of short ones (mix_na < 0: off)
+    int mix_na, mix_sa;
     // fused SwiGLU (gemm3 only): 1 = forward (C = h [M][2*inner], glu_aux = act [M][inner]); 2 = backward (acc = dact,
     // glu_aux = h, C = dh [M][2*inner], glu_dbias += column sums of dh)
     int glu_mode, glu_inner;

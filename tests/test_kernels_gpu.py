@@ -582,6 +582,24 @@ def test_gemv_single_row(ops, dev, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mix", [None, "1,3", "2,5", "3,12", "2,0"])
+def test_wgrad_mixed_split_k(ops, dev, mix, monkeypatch):
+    """weight-gradient GEMM (TN, fp32, atomics) with some tiles cut into sa and the others into sa + 1 K slices (1-D grid,
+    long slices first): same result as fp32 matmul for forced plans and for the planner's own choice"""
+    if mix:
+        monkeypatch.setenv("KALLE_GEMM_MIX", mix)
+    M, N, K = 768, 1024, 8192                                            # 12 tiles of 256 x 256, 128 K-tiles
+    dy = (_mk((K, M), dev, seed=150) * 0.5).bfloat16()
+    x = (_mk((K, N), dev, seed=151) * 0.5).bfloat16()
+    ref = dy.float().T @ x.float()
+    got = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)
+    assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+    acc = torch.ones(M, N, device=dev)
+    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=acc, accumulate=True)
+    assert rel_l2(acc, ref + 1.0) < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,K", [(16384, 2048), (2048 + 512, 2048), (4098, 264), (1030, 8192)])
 def test_gemv_rows_per_wave_and_bias(ops, dev, N, K):
     """wide outputs walk several row pairs per wave; a Linear bias rides in the residual slot of the single-row kernel"""
