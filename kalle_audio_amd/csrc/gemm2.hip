@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <functional>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -702,27 +704,29 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     // (288 tiles x 3 slices = 3.4 rounds -> 4 with uniform splitting).  The plan comes from replaying the dispatch on 256 CUs
     // (time of a slice = 10 us + 1.6 us per K-tile, atomics at 2 TB/s - fitted to tools/wgrad_sweep.py) and is cached per shape.
     if (can_split && best_bn == 256 && !tile_env && !getenv("KALLE_GEMM_NOMIX")) {
-        struct Plan { int M, N, K, sa, na; };
+        struct Plan { int M, N, kb, sa, na; };          // kb: K-tiles / 16 (a plan is valid for any K; nearby K share it)
         static thread_local Plan cache[32];
-        static thread_local int ncache = 0;
+        static thread_local int ncache = 0, victim = 0;
         const Plan* hit = nullptr;
         int sa_sel = 0, na_sel = -1;
         for (int i = 0; i < ncache; ++i)
-            if (cache[i].M == p.M && cache[i].N == p.N && cache[i].K == p.K) hit = &cache[i];
+            if (cache[i].M == p.M && cache[i].N == p.N && cache[i].kb == nk / 16) hit = &cache[i];
         if (!hit) {
             const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
             auto replay = [&](int sa, int na) {        // makespan (us) of the dispatch order on 256 CUs + atomic traffic
-                double cu[256] = {0.0};
+                double cu[256];                         // min-heap of the times at which the CUs fall free
+                for (int c = 0; c < 256; ++c) cu[c] = 0.0;
                 auto run = [&](int tiles, int slices) {
                     if (tiles <= 0 || slices <= 0) return;
                     const int per = (nk + slices - 1) / slices;
                     for (int sl = 0; sl < slices; ++sl) {
                         const int k = nk - sl * per < per ? nk - sl * per : per;
                         if (k <= 0) break;
+                        const double d = 10.0 + 1.6 * k;
                         for (int t = 0; t < tiles; ++t) {
-                            int m = 0;
-                            for (int c = 1; c < 256; ++c) if (cu[c] < cu[m]) m = c;
-                            cu[m] += 10.0 + 1.6 * k;
+                            std::pop_heap(cu, cu + 256, std::greater<double>());
+                            cu[255] += d;
+                            std::push_heap(cu, cu + 256, std::greater<double>());
                         }
                     }
                 };
@@ -733,29 +737,31 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
                 const double savg = ((double)na * sa + (double)(ntiles - na) * (sa + 1)) / ntiles;
                 return mk + (savg > 1.0 ? savg * p.M * p.N * 4.0 / 2.0e12 * 1e6 : 0.0);
             };
-            Plan best_plan{p.M, p.N, p.K, 0, -1};
+            Plan best_plan{p.M, p.N, nk / 16, 0, -1};
             double t_uniform = 1e30, t_best = 1e30;
-            const int step = ntiles > 64 ? 16 : 4;
-            for (int sa = 0; sa <= 7; ++sa) {
+            const int step = ntiles / 12 > 4 ? (ntiles / 12 + 3) & ~3 : 4;
+            // uniform plans: every slice count; mixed plans: around the uniform model's choice (best_s slices)
+            for (int sl = 1; sl <= 16 && (sl == 1 || nk / sl >= 8); ++sl) {
+                const double t = replay(sl - 1, 0);
+                if (t < t_uniform) t_uniform = t;
+            }
+            for (int sa = best_s > 3 ? best_s - 3 : 1; sa <= best_s + 1 && sa <= 15; ++sa) {
                 if (nk / (sa + 1) < 8) break;
-                for (int na = 0; na <= (sa == 0 ? 0 : ntiles); na += step) {
+                for (int na = step; na < ntiles; na += step) {
                     const double t = replay(sa, na);
-                    if (na == 0 && t < t_uniform) t_uniform = t;       // (na = 0: uniform sa + 1 slices)
                     if (t < t_best) { t_best = t; best_plan.sa = sa; best_plan.na = na; }
                 }
             }
-            for (int s = 9; s <= 16 && nk / s >= 8; ++s) {                 // uniform plans beyond the mixed range
-                const double t = replay(s - 1, 0);
-                if (t < t_uniform) t_uniform = t;
-            }
             if (!(best_plan.na > 0 && t_best < 0.97 * t_uniform)) best_plan.na = -1;   // not worth leaving the uniform plan
             if (ncache < 32) cache[ncache++] = best_plan;
+            else { cache[victim] = best_plan; victim = (victim + 1) & 31; }
             sa_sel = best_plan.sa;
             na_sel = best_plan.na;
         } else {
             sa_sel = hit->sa;
             na_sel = hit->na;
         }
+        if (na_sel > 0 && nk / (sa_sel + 1) < 8) na_sel = -1;    // (a cached plan of a longer K)
         if (getenv("KALLE_GEMM_DEBUG")) fprintf(stderr, "[kalle gemm] %d x %d x %d: mixed split sa=%d na=%d (hit=%d)\n", p.M, p.N, p.K, sa_sel, na_sel, hit != nullptr);
         if (na_sel > 0) { p.mix_na = na_sel; p.mix_sa = sa_sel; best_s = sa_sel + 1; }
     }
