@@ -197,7 +197,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    // causal: the last query block streams the most key blocks - dispatch the heavy workgroups first
+    const int b = blockIdx.z, h = blockIdx.y, q0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
     const int hk = h / (p.H / p.Hkv);
 
     const bf16_t* qsrc = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + h * 64;
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
     const int g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z;
     const int group = p.H / p.Hkv;
-    const int o0 = blockIdx.x * 128;  // owner block start
+    // owner block start (dQ kernel with causal masking: heavy query blocks - the last ones - first)
+    const int o0 = (!KV && p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
     const int hown = blockIdx.y;      // kv head (KV) or q head (!KV)
     const int hk = KV ? hown : hown / group;
 
