@@ -246,11 +246,14 @@ class TransformerBlockFn(torch.autograd.Function):
         S = 0
         if context is not None and blk.cross_attend:
             S = context.shape[1]
-            ctxb = _to_bf16(context.contiguous()).view(B * S, context.shape[-1])
+            # ContinuousTransformer leaves ONE bf16 copy of a trainable fp32 context on the tensor for all its layers
+            pre = getattr(context, "_kalle_bf16", None)
+            ctxb = (pre if pre is not None else _to_bf16(context.contiguous())).view(B * S, context.shape[-1])
         gc = _to_f32(global_cond.contiguous()) if global_cond is not None else None
         p = D.block_params(blk)
         y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S)
         ctx.blk, ctx.sv, ctx.ctxb = blk, sv, ctxb
+        ctx.context_ref = context if (context is not None and hasattr(context, "_kalle_dctx")) else None
         ctx.masks = (mask8, cmask8, rope)
         ctx.dims = (B, N, S, Dm)
         ctx.dtypes = (x.dtype, context.dtype if context is not None else None,
@@ -274,9 +277,19 @@ class TransformerBlockFn(torch.autograd.Function):
             g_bf16 = sh[1]
         if len(_GRAD_SHADOW) > 8:
             _GRAD_SHADOW.clear()
+        # The context feeds every layer: instead of 24 fp32 gradients that autograd adds up one by one, the first backward
+        # to run creates the gradient, returns THAT tensor, and the later ones accumulate into it in the GEMM epilogue and
+        # return None (the producer of the context runs its backward only after every layer has contributed).
+        cref = ctx.context_ref
+        acc = cref._kalle_dctx.get("acc") if (cref is not None and ctx.needs_input_grad[2] and ctx.dtypes[1] == F32) else None
         dx, dctx, dglobal, go, dxb = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
                                                  want_dctx=ctx.needs_input_grad[2], g_bf16=g_bf16,
-                                                 want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx))
+                                                 want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx), dctx_acc=acc)
+        if cref is not None and ctx.needs_input_grad[2] and ctx.dtypes[1] == F32 and dctx is not None:
+            if acc is None:
+                cref._kalle_dctx["acc"] = dctx        # first contribution: this tensor is the gradient
+            else:
+                dctx = None                           # accumulated in place
         if dxb is not None:
             _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb)
         gr = go.grads

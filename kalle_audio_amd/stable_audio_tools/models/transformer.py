@@ -234,6 +234,11 @@ class ContinuousTransformer(nn.Module):
         if ctx is not None and not ctx.requires_grad and ctx.dtype == torch.float32:
             # frozen conditioning (T5 / number embedders): one bf16 cast for all layers instead of one per layer
             kwargs = dict(kwargs, context=KF._to_bf16(ctx.contiguous()))
+        elif ctx is not None and ctx.dtype == torch.float32 and ctx.is_cuda:
+            # trainable conditioning (to_cond_embed, dit.py:49-53): the fp32 tensor stays the autograd input of every layer;
+            # its bf16 copy is made once and rides on it, and the layers share one gradient accumulator (functional.py)
+            ctx._kalle_bf16 = KF._to_bf16(ctx.detach().contiguous())
+            ctx._kalle_dctx = {}
         for layer in self.layers:
             x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
             if return_info:
