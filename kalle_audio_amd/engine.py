@@ -234,10 +234,18 @@ class DataParallelTrainer:
         # ONE clear of the flat gradient per optimizer step; every gradient kernel then accumulates into its sink.  (Letting
         # the first micro-batch overwrite instead costs a separate small clear in front of each split-K weight gradient and
         # column sum: ~300 launches and twice the time of this single pass.)
+        # That only pays when the weight gradients are split-K GEMMs (K = tokens of the micro-batch >= ~8 k): a weight gradient
+        # that writes its output whole would have to read the cleared buffer back instead (B = 16: -5 %), so small
+        # micro-batches keep the overwrite-on-first-micro-batch rule.
+        rows = max((getattr(blk, "_kalle_last_rows", 0) for _, blk in self.blocks), default=0)
+        clear_once = rows >= 8192
         for _, blk in self.blocks:
-            blk._kalle_grad_accumulate = True
+            blk._kalle_grad_accumulate = True if clear_once else not first
         if first:
-            self.flat.grad.zero_()
+            if clear_once:
+                self.flat.grad.zero_()
+            elif "_rest" in self.flat.bucket_range:
+                self.flat.bucket_grad("_rest").zero_()     # autograd accumulates (+=) into these views
         loss.backward()
         self._finish_comm()
         if self._boundary():

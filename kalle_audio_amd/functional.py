@@ -253,6 +253,7 @@ class TransformerBlockFn(torch.autograd.Function):
         p = D.block_params(blk)
         y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S)
         ctx.blk, ctx.sv, ctx.ctxb = blk, sv, ctxb
+        blk._kalle_last_rows = B * N                    # (the trainer picks its gradient-clearing rule from it)
         ctx.context_ref = context if (context is not None and hasattr(context, "_kalle_dctx")) else None
         ctx.masks = (mask8, cmask8, rope)
         ctx.dims = (B, N, S, Dm)

@@ -37,6 +37,7 @@ class LlamaLayerFn(torch.autograd.Function):
         p = LO.layer_params(layer)
         y, sv = LO.layer_fwd(p, x.contiguous().view(B * L, Dm), B, L, rope, mask8)
         ctx.layer, ctx.sv, ctx.aux, ctx.dims = layer, sv, (mask8, rope), (B, L, Dm)
+        layer._kalle_last_rows = B * L                  # (the trainer picks its gradient-clearing rule from it)
         return y.view(B, L, Dm)
 
     @staticmethod
