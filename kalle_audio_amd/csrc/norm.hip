@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         const int64_t mb = (int64_t)(row / rpb) * ld_mod;
-        float xh[NCH][8], dh[NCH][8];
+        float xh[NCH][8], dh[NCH][8], rv[NCH][8];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float xv[8], d[8];
                 load8<XF32>(x, (int64_t)row * D + col, xv);
                 load8<false>(dy, (int64_t)row * D + col, d);
+                // the residual-stream gradient travels with x and dy (issued after the reductions it would expose a second
+                // load latency per row: it may alias dx, so the compiler cannot move it up by itself)
+                if (dres) load8<true>(dres, (int64_t)row * D + col, rv[j]);
                 if (scale) {
                     float sc[8];
                     load8<true>(scale, mb + col, sc);
@@ -163,10 +166,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rs * (dh[j][e] - c1 - xh[j][e] * c2);
                 if (dres) {
-                    float r[8];
-                    load8<true>(dres, (int64_t)row * D + col, r);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                    for (int e = 0; e < 8; ++e) o[e] += rv[j][e];
                 }
                 store8<true>(dx, (int64_t)row * D + col, o);
                 if (dxb) store8<false>(dxb, (int64_t)row * D + col, o);
