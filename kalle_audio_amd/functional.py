@@ -254,7 +254,8 @@ class TransformerBlockFn(torch.autograd.Function):
         y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S)
         ctx.blk, ctx.sv, ctx.ctxb = blk, sv, ctxb
         blk._kalle_last_rows = B * N                    # (the trainer picks its gradient-clearing rule from it)
-        ctx.context_ref = context if (context is not None and hasattr(context, "_kalle_dctx")) else None
+        # (the accumulator dict of THIS forward pass: a second forward over the same context tensor gets a new one)
+        ctx.dctx_state = getattr(context, "_kalle_dctx", None) if context is not None else None
         ctx.masks = (mask8, cmask8, rope)
         ctx.dims = (B, N, S, Dm)
         ctx.dtypes = (x.dtype, context.dtype if context is not None else None,
@@ -281,14 +282,14 @@ class TransformerBlockFn(torch.autograd.Function):
         # The context feeds every layer: instead of 24 fp32 gradients that autograd adds up one by one, the first backward
         # to run creates the gradient, returns THAT tensor, and the later ones accumulate into it in the GEMM epilogue and
         # return None (the producer of the context runs its backward only after every layer has contributed).
-        cref = ctx.context_ref
-        acc = cref._kalle_dctx.get("acc") if (cref is not None and ctx.needs_input_grad[2] and ctx.dtypes[1] == F32) else None
+        dst = ctx.dctx_state if (ctx.needs_input_grad[2] and ctx.dtypes[1] == F32) else None
+        acc = dst.get("acc") if dst is not None else None
         dx, dctx, dglobal, go, dxb = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
                                                  want_dctx=ctx.needs_input_grad[2], g_bf16=g_bf16,
                                                  want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx), dctx_acc=acc)
-        if cref is not None and ctx.needs_input_grad[2] and ctx.dtypes[1] == F32 and dctx is not None:
+        if dst is not None and dctx is not None:
             if acc is None:
-                cref._kalle_dctx["acc"] = dctx        # first contribution: this tensor is the gradient
+                dst["acc"] = dctx                     # first contribution: this tensor is the gradient
             else:
                 dctx = None                           # accumulated in place
         if dxb is not None:
