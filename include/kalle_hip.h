@@ -98,6 +98,13 @@ int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float*
                         const float* mean, const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
                         float* dgamma_part, float* dbeta_part, int rows, int D, void* stream);
 
+/* same, with the parameter gradients added ATOMICALLY into [D] accumulators (dgamma_acc, dbeta_acc or NULL) that the
+ * caller has initialised - the trainer's flat gradient: no partial rows, no reduction launch */
+int kalle_layernorm_bwd_acc(const void* dy, const void* x, int x_dtype, const float* gamma,
+                            const float* scale, int64_t ld_mod, int rows_per_batch,
+                            const float* mean, const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
+                            float* dgamma_acc, float* dbeta_acc, int rows, int D, void* stream);
+
 /* adaLN modulation gradients: dscale[b,d] = sum_t dy*ln, dshift[b,d] = sum_t dy   (transformer.py:665,679) */
 int kalle_adaln_mod_bwd(const void* dy, const void* x, int x_dtype, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dscale, float* dshift, int64_t ld_mod,

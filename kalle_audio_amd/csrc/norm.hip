@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      int64_t ld_mod, int rpb, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dres, float* dx,
                                                      bf16_t* __restrict__ dxb,
-                                                     float* __restrict__ dgp, float* __restrict__ dbp, int rows, int D) {
+                                                     float* __restrict__ dgp, float* __restrict__ dbp, int rows, int D,
+                                                     int atomic) {
     __shared__ float red[4][64 * 8 + 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NCH][8], ab[NCH][8], g[NCH][8];
@@ -186,8 +187,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (outp) {
                 for (int i = threadIdx.x; i < 512; i += 256) {
                     const int col = j * 512 + i;
-                    if (col < D)
-                        outp[(int64_t)blockIdx.x * D + col] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                    if (col < D) {
+                        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                        if (atomic) atomicAdd(outp + col, v);      // straight into the [D] accumulator: no reduction pass
+                        else outp[(int64_t)blockIdx.x * D + col] = v;
+                    }
                 }
             }
         }
@@ -403,11 +407,32 @@ extern "C" int kalle_layernorm_bwd_parts(int rows) {
     return b < LN_BWD_MAX_BLOCKS ? (b > 0 ? b : 1) : LN_BWD_MAX_BLOCKS;
 }
 
+static int ln_bwd_launch(const void* dy, const void* x, int x_dtype, const float* gamma, const float* scale,
+                         int64_t ld_mod, int rows_per_batch, const float* mean, const float* rstd, const float* dres,
+                         float* dx_out, void* dx_bf16, float* dgamma_part, float* dbeta_part, int rows, int D, int atomic,
+                         void* stream);
+
 extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* gamma,
                                    const float* scale, int64_t ld_mod, int rows_per_batch, const float* mean,
                                    const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
                                    float* dgamma_part,
                                    float* dbeta_part, int rows, int D, void* stream) {
+    return ln_bwd_launch(dy, x, x_dtype, gamma, scale, ld_mod, rows_per_batch, mean, rstd, dres, dx_out, dx_bf16,
+                         dgamma_part, dbeta_part, rows, D, 0, stream);
+}
+
+extern "C" int kalle_layernorm_bwd_acc(const void* dy, const void* x, int x_dtype, const float* gamma,
+                                       const float* scale, int64_t ld_mod, int rows_per_batch, const float* mean,
+                                       const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
+                                       float* dgamma_acc, float* dbeta_acc, int rows, int D, void* stream) {
+    return ln_bwd_launch(dy, x, x_dtype, gamma, scale, ld_mod, rows_per_batch, mean, rstd, dres, dx_out, dx_bf16,
+                         dgamma_acc, dbeta_acc, rows, D, 1, stream);
+}
+
+static int ln_bwd_launch(const void* dy, const void* x, int x_dtype, const float* gamma, const float* scale,
+                         int64_t ld_mod, int rows_per_batch, const float* mean, const float* rstd, const float* dres,
+                         float* dx_out, void* dx_bf16, float* dgamma_part, float* dbeta_part, int rows, int D, int atomic,
+                         void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx_out || rows <= 0 || (D & 7) || D <= 0 || D > 4096)
         return KALLE_ERR_ARG;
     const int rpb = rows_per_batch > 0 ? rows_per_batch : 1;
@@ -417,11 +442,11 @@ extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, c
     if (x_dtype == KALLE_F32)                                                                                     \
         KALLE_LAUNCH((ln_bwd_kernel<N, true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma, \
                            scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16), dgamma_part,   \
-                           dbeta_part, rows, D);                                                                   \
+                           dbeta_part, rows, D, atomic);                                                           \
     else                                                                                                          \
         KALLE_LAUNCH((ln_bwd_kernel<N, false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,      \
                            gamma, scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16),         \
-                           dgamma_part, dbeta_part, rows, D);
+                           dgamma_part, dbeta_part, rows, D, atomic);
     DISPATCH_NCH(D, CALL);
 #undef CALL
     return kalle_check_launch();

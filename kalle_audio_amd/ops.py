@@ -5,6 +5,7 @@ stream and returns immediately.  Nothing here falls back to torch math: CPU tens
 PyTorch is used only for device memory and streams.
 """
 import ctypes
+import os
 
 import torch
 
@@ -140,12 +141,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=N
     lib = _lib.load()
     rows, D = _rows2d(x)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
-    nparts = lib.kalle_layernorm_bwd_parts(rows)
-    dgp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
-    dbp = torch.empty((nparts, D), device=x.device, dtype=torch.float32) if want_dbeta else None
     if dx_out is None:
         dx_out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     ld_mod = scale.stride(-2) if scale is not None else 0
+    if dgamma_out is not None and accumulate and not want_dbeta and os.environ.get("KALLE_LN_ATOMIC", "1") != "0":
+        # trainer mode: the gradient sink already holds this step's running sum - add into it from the kernel
+        check(lib.kalle_layernorm_bwd_acc(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
+                                          _p(rstd), _p(dres), _p(dx_out), _p(dx_bf16), _p(dgamma_out), None, rows, D,
+                                          _stream()), "kalle_layernorm_bwd_acc")
+        return dx_out, dgamma_out, None
+    nparts = lib.kalle_layernorm_bwd_parts(rows)
+    dgp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
+    dbp = torch.empty((nparts, D), device=x.device, dtype=torch.float32) if want_dbeta else None
     check(lib.kalle_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
                                   _p(rstd), _p(dres), _p(dx_out), _p(dx_bf16), _p(dgp), _p(dbp), rows, D, _stream()),
           "kalle_layernorm_bwd")
