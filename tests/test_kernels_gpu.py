@@ -600,6 +600,22 @@ def test_wgrad_mixed_split_k(ops, dev, mix, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N", [(12288, 1536), (1536, 6144), (4608, 1536)])
+def test_wgrad_planned_split_k_at_bench_shapes(ops, dev, M, N):
+    """the weight-gradient shapes of the bench step (K = 32256 tokens) under the planner's own split-K choice (mixed for the
+    two feed-forward shapes): against fp64-accumulated fp32 matmul, and accumulation on top of an existing gradient"""
+    K = 32256
+    dy = (_mk((K, M), dev, seed=160) * 0.25).bfloat16()
+    x = (_mk((K, N), dev, seed=161) * 0.25).bfloat16()
+    ref = (dy.float().T.double() @ x.float().double()).float()
+    out = torch.full((M, N), 3.0, device=dev)
+    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out)                     # overwrites (clears C itself)
+    assert rel_l2(out, ref) < 3e-6, rel_l2(out, ref)
+    ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=True)    # adds on top
+    assert rel_l2(out, 2 * ref) < 3e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,K", [(16384, 2048), (2048 + 512, 2048), (4098, 264), (1030, 8192)])
 def test_gemv_rows_per_wave_and_bias(ops, dev, N, K):
     """wide outputs walk several row pairs per wave; a Linear bias rides in the residual slot of the single-row kernel"""
