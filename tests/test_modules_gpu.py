@@ -545,6 +545,17 @@ def test_full_size_dit_step_properties(dev):
     la, ga = grads(tr, slice(0, 4), accum_parts=2)                            # (2) the flat gradient holds the SUM of the
     assert abs(la - l1) < 2e-3 * abs(l1)                                      # micro-batch gradients (1/accum is folded
     assert rel(ga * 0.5, g1) < 2e-2, rel(ga * 0.5, g1)                        # into the fused Adam step)
+    # (2b) a micro-batch of >= 8192 tokens takes the other gradient-clearing rule (ONE clear of the flat gradient, every
+    # kernel accumulates, LayerNorm gamma gradients added atomically, mixed split-K weight gradients): it must agree with the
+    # same batch run as two micro-batches under the overwrite-on-first-micro-batch rule
+    lat_b, noise_b, t_b, cond_b = bench.make_batch(72, dev, 7)
+    lat, noise, t, cond = lat_b, noise_b, t_b, cond_b                         # (grads() reads these)
+    lw, gw = grads(tr, slice(0, 72))                                          # 72 x 126 = 9072 rows
+    assert max(getattr(blk, "_kalle_last_rows", 0) for _, blk in tr.blocks) >= 8192
+    lh, gh = grads(tr, slice(0, 72), accum_parts=2)                           # 2 x 4536 rows
+    assert abs(lh - lw) < 2e-3 * abs(lw)
+    assert rel(gh * 0.5, gw) < 2e-2, rel(gh * 0.5, gw)
+    lat, noise, t, cond = bench.make_batch(4, dev, 99)
     tr.lr, tr.grad_accum_steps, tr.micro = 1e-4, 1, 0                          # (3)
     before = tr.train_step(model, lat, t, noise, cond, objective="v").item()   # loss, then the first update
     after = tr.train_step(model, lat, t, noise, cond, objective="v").item()
