@@ -119,6 +119,11 @@ int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, 
                       int rows_per_batch, const float* rrms, float* dx, float* dscale_part, const float* dres,
                       void* dx_bf16, int rows, int D, void* stream);
 
+/* same, with dscale added ATOMICALLY into the caller-initialised [D] accumulator dscale_acc (the trainer's flat gradient) */
+int kalle_rmsnorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale, int64_t ld_scale,
+                          int rows_per_batch, const float* rrms, float* dx, float* dscale_acc, const float* dres,
+                          void* dx_bf16, int rows, int D, void* stream);
+
 /* column sums: out[c] (+)= sum_r in[r][c]; in fp32 or bf16 [rows][ld]. Used for bias grads and partial reduces. */
 int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out, int rows, int cols, int accumulate,
                  void* stream);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
                                                       const float* __restrict__ scale, int64_t ld_scale, int rpb,
                                                       const float* __restrict__ rrms, float* __restrict__ dx,
                                                       float* __restrict__ dsp, const float* __restrict__ dres,
-                                                      bf16_t* __restrict__ dxb, int rows, int D) {
+                                                      bf16_t* __restrict__ dxb, int rows, int D, int atomic) {
     __shared__ float red[4][64 * 8 + 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float as[NCH][8];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float rr = rrms[row];
         const int64_t sb = (int64_t)(row / rpb) * ld_scale;
-        float xv[NCH][8], dh[NCH][8];
+        float xv[NCH][8], dh[NCH][8], rv[NCH][8];
         float c = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
                 load8<XF32>(x, (int64_t)row * D + col, xv[j]);
                 load8<DYF32>(dy, (int64_t)row * D + col, d);
                 load8<true>(scale, sb + col, s);
+                if (dres) load8<true>(dres, (int64_t)row * D + col, rv[j]);   // (with x and dy: one latency per row)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     as[j][e] += d[e] * xv[j][e] * rr;
@@ -311,10 +312,8 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = dh[j][e] * rr - xv[j][e] * c;
                 if (dres) {   // fused residual-stream gradient add
-                    float rsd[8];
-                    load8<true>(dres, (int64_t)row * D + col, rsd);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += rsd[e];
+                    for (int e = 0; e < 8; ++e) o[e] += rv[j][e];
                 }
                 store8<true>(dx, (int64_t)row * D + col, o);
                 if (dxb) store8<false>(dxb, (int64_t)row * D + col, o);
@@ -330,7 +329,11 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const void* __restrict__ d
         if (dsp) {
             for (int i = threadIdx.x; i < 512; i += 256) {
                 const int col = j * 512 + i;
-                if (col < D) dsp[(int64_t)blockIdx.x * D + col] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                if (col < D) {
+                    const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                    if (atomic) atomicAdd(dsp + col, v);
+                    else dsp[(int64_t)blockIdx.x * D + col] = v;
+                }
             }
         }
     }
@@ -492,10 +495,26 @@ extern "C" int kalle_rmsnorm_fwd(const void* x, int x_dtype, const float* scale,
     return kalle_check_launch();
 }
 
+static int rms_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale, int64_t ld_scale,
+                          int rows_per_batch, const float* rrms, float* dx, float* dscale_part, const float* dres,
+                          void* dx_bf16, int rows, int D, int atomic, void* stream);
 extern "C" int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale,
                                  int64_t ld_scale, int rows_per_batch, const float* rrms, float* dx,
                                  float* dscale_part, const float* dres, void* dx_bf16, int rows, int D,
                                  void* stream) {
+    return rms_bwd_launch(dy, dy_dtype, x, x_dtype, scale, ld_scale, rows_per_batch, rrms, dx, dscale_part, dres, dx_bf16,
+                          rows, D, 0, stream);
+}
+extern "C" int kalle_rmsnorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale,
+                                     int64_t ld_scale, int rows_per_batch, const float* rrms, float* dx,
+                                     float* dscale_acc, const float* dres, void* dx_bf16, int rows, int D,
+                                     void* stream) {
+    return rms_bwd_launch(dy, dy_dtype, x, x_dtype, scale, ld_scale, rows_per_batch, rrms, dx, dscale_acc, dres, dx_bf16,
+                          rows, D, 1, stream);
+}
+static int rms_bwd_launch(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* scale, int64_t ld_scale,
+                          int rows_per_batch, const float* rrms, float* dx, float* dscale_part, const float* dres,
+                          void* dx_bf16, int rows, int D, int atomic, void* stream) {
     if (!dy || !x || !scale || !rrms || !dx || rows <= 0 || D <= 0 || (D & 7) || D > 4096) return KALLE_ERR_ARG;
     const int rpb = rows_per_batch > 0 ? rows_per_batch : rows;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -503,16 +522,16 @@ extern "C" int kalle_rmsnorm_bwd(const void* dy, int dy_dtype, const void* x, in
 #define CALL(N)                                                                                                     \
     if (x_dtype == KALLE_F32 && dy_dtype == KALLE_F32)                                                              \
         KALLE_LAUNCH((rms_bwd_kernel<N, true, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms,  \
-                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D, atomic);                          \
     else if (x_dtype == KALLE_F32)                                                                                  \
         KALLE_LAUNCH((rms_bwd_kernel<N, true, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
-                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D, atomic);                          \
     else if (dy_dtype == KALLE_F32)                                                                                 \
         KALLE_LAUNCH((rms_bwd_kernel<N, false, true>), grid, block, 0, st, dy, x, scale, ld_scale, rpb, rrms, \
-                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);                          \
+                           dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D, atomic);                          \
     else                                                                                                            \
         KALLE_LAUNCH((rms_bwd_kernel<N, false, false>), grid, block, 0, st, dy, x, scale, ld_scale, rpb,      \
-                           rrms, dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D);
+                           rrms, dx, dscale_part, dres, static_cast<bf16_t*>(dx_bf16), rows, D, atomic);
     DISPATCH_NCH(D, CALL);
 #undef CALL
     return kalle_check_launch();

@@ -188,10 +188,15 @@ def rmsnorm_bwd(dy, x, scale, rrms, rows_per_batch=0, dres=None, dx_bf16=None, d
     lib = _lib.load()
     rows, D = _rows2d(x)
     dy = dy.contiguous()
-    nparts = lib.kalle_layernorm_bwd_parts(rows)
-    dsp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
     dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     ld = scale.stride(-2) if scale.dim() >= 2 else 0
+    if dscale_out is not None and accumulate and ld == 0:
+        # trainer mode: add into the gradient sink from the kernel (no partial rows, no reduction launch)
+        check(lib.kalle_rmsnorm_bwd_acc(_p(dy), _dt(dy), _p(x), _dt(x), _p(scale), ld, rows_per_batch, _p(rrms), _p(dx),
+                                        _p(dscale_out), _p(dres), _p(dx_bf16), rows, D, _stream()), "kalle_rmsnorm_bwd_acc")
+        return dx, None
+    nparts = lib.kalle_layernorm_bwd_parts(rows)
+    dsp = torch.empty((nparts, D), device=x.device, dtype=torch.float32)
     check(lib.kalle_rmsnorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(scale), ld, rows_per_batch, _p(rrms), _p(dx),
                                 _p(dsp), _p(dres), _p(dx_bf16), rows, D, _stream()), "kalle_rmsnorm_bwd")
     if dscale_out is not None:
