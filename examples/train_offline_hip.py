@@ -91,10 +91,11 @@ def main():
 
     total = int(config.get("total_steps", 10 ** 9))
     warm = int(config.get("warmup_steps", 0))
+    step0 = step       # resume offset, bound once: the trainer passes its own optimizer-step count (1, 2, ...) as `s`
     trainer = engine.DataParallelTrainer(
         model, lr=config["lr"], optimizer="AdamW", weight_decay=config["weight_decay"],
         grad_accum_steps=config["gradient_accumulation_steps"],
-        lr_schedule=lambda s: engine.cosine_with_warmup(s + step, warm, total))
+        lr_schedule=lambda s: engine.cosine_with_warmup(s + step0, warm, total))
 
     if args.synthetic:
         B, L = args.synthetic
@@ -123,7 +124,7 @@ def main():
         step += 1
         if step % config["log_interval"] == 0 and rank == 0:               # the only host syncs: the logged scalars
             print(f"[{datetime.datetime.now():%H:%M:%S}] epoch {epoch} step {step} lr "
-                  f"{config['lr'] * engine.cosine_with_warmup(step, warm, total):.3e} "
+                  f"{trainer.last_lr:.3e} "
                   f"audio_loss {out['audio_loss'].item():.4f} end_loss {out['end_loss'].item():.4f}", flush=True)
         if step % int(config.get("save_interval", 10 ** 9)) == 0 and rank == 0:
             torch.save(model.state_dict(), os.path.join(config["output_dir"], f"epoch_{epoch}_step_{step}.pt"))

@@ -813,11 +813,8 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
         return kalle_check_launch();
     }
     constexpr int lds = 3 * AT_TILE + 128 * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(attn_fwd_kernel<1>), lds, lds_ok);
     dim3 grid((Nq + 127) / 128, H, B), block(512);
     KALLE_LAUNCH(attn_fwd_kernel<1>, grid, block, lds, static_cast<hipStream_t>(stream), p);
     return kalle_check_launch();
@@ -846,14 +843,9 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 
     constexpr int lds = 2 * AT_TILE + 256 * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> lds_ok_kv{0}, lds_ok_q{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_kernel<true, 1>), lds, lds_ok_kv);
+    kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_kernel<false, 1>), lds, lds_ok_q);
     // dQ first: it also produces delta, which the dK/dV kernel streams
     KALLE_LAUNCH((attn_bwd_kernel<false, 1>), dim3((Nq + 127) / 128, H, B), dim3(512), lds, st, p);
     KALLE_LAUNCH((attn_bwd_kernel<true, 1>), dim3((Nk + 127) / 128, Hkv, B), dim3(512), lds, st, p);

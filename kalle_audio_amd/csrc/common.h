@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define KALLE_OK 0
 #define KALLE_ERR_ARG -1      // bad shape / alignment / null pointer
 #define KALLE_ERR_LAUNCH -2   // hipLaunch failure
@@ -77,6 +79,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
         (void)hipGetLastError();     \
         hipLaunchKernelGGL(__VA_ARGS__); \
     } while (0)
+
+// Kernels that ask for more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, which is a
+// per-DEVICE property of the function: set once per (kernel, device), any thread.  `done` is the launch site's own
+// bitmask over device ordinals (a benign race sets the attribute twice).
+static inline void kalle_allow_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
 
 extern "C" void kalle_set_last_error(const char* what);
 static inline int kalle_check_launch() {

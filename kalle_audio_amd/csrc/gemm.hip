@@ -247,12 +247,8 @@ int launch(const GemmParams& p, hipStream_t st) {
     constexpr int pipe = 2 * (A_BYTES + B_BYTES);
     constexpr int epi = BM * EP_LD * 4;
     constexpr int lds = pipe > epi ? pipe : epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<A_KM, B_KM, C_F32>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<A_KM, B_KM, C_F32>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     KALLE_LAUNCH((gemm_bf16_kernel<A_KM, B_KM, C_F32>), grid, block, lds, st, p);
     return kalle_check_launch();

@@ -471,12 +471,8 @@ template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
 int launch2(const GemmParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     constexpr int lds = 3 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 64);
     KALLE_LAUNCH((gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), grid, block, lds, st, p);
     return kalle_check_launch();
@@ -608,12 +604,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
 template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
 int launch3(const GemmParams& p, hipStream_t st) {
     constexpr int lds = 2 * (256 + 256) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32, GLU>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32, GLU>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
     if (p.mix_na >= 0) {
         const int ntiles = p.tiles_m * p.tiles_n;

@@ -44,9 +44,17 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
                 st["step"] += 1
                 grad = p.grad if p.grad.dtype == torch.float32 else p.grad.float()
-                ops.adam_step(p.data, grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], None, lr=g["lr"],
-                              beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
-                              decoupled=g["adam_w_mode"], step=st["step"])
+                # The kernel writes the weights through the raw pointer, so p._version does not move and the bf16 compute
+                # copy that dit_ops.bf16_of caches per parameter version would go stale: a live copy is updated by the same
+                # launch (param_bf16), anything else is dropped so the next forward re-casts.
+                c = getattr(p, "_kalle_bf16", None)
+                live = (c is not None and getattr(p, "_kalle_bf16_pinned", None) is None and c[0] == p._version
+                        and c[1].device == p.device and c[1].is_contiguous() and p.is_contiguous())
+                ops.adam_step(p.data, grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], c[1] if live else None,
+                              lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
+                              weight_decay=g["weight_decay"], decoupled=g["adam_w_mode"], step=st["step"])
+                if c is not None and not live:
+                    del p._kalle_bf16
         return loss
 
 
@@ -54,7 +62,7 @@ def cosine_with_warmup(step, warmup_steps, total_steps):
     """transformers.get_cosine_schedule_with_warmup (train_offline.py:99-104) as a pure function of the step."""
     if step < warmup_steps:
         return step / max(1, warmup_steps)
-    prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)   # (past total_steps transformers' lambda rises again: kept)
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
 
 
@@ -169,6 +177,7 @@ class DataParallelTrainer:
         self.comm_dtype = comm_dtype
         self.step_count = 0
         self.micro = 0
+        self.last_lr = lr
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         device = named[0][1].device
         # bucket key: the owning TransformerBlock's module path, or "_rest"
@@ -273,7 +282,11 @@ class DataParallelTrainer:
 
     def optimizer_step(self):
         self.step_count += 1
-        lr = self.lr * (self.lr_schedule(self.step_count) if self.lr_schedule else 1.0)
+        # lr_schedule(s): multiplier for the optimizer step taken after `s` completed ones - torch LambdaLR's convention,
+        # so the k-th step (k = 1, 2, ...) uses lr_lambda(k - 1) exactly as optimizer.step(); scheduler.step() does
+        # (train_offline.py:247-248)
+        lr = self.lr * (self.lr_schedule(self.step_count - 1) if self.lr_schedule else 1.0)
+        self.last_lr = lr                                  # what this optimizer step actually used (for logging)
         f = self.flat
         ops.adam_step(f.param, f.grad, self.exp_avg, self.exp_avg_sq, f.param_bf16, lr=lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, decoupled=self.decoupled,

@@ -225,9 +225,28 @@ class SpliceFn(torch.autograd.Function):
         return dpre, dtok.to(tdt)
 
 
-# bf16 shadows of residual-stream gradients handed from block i+1's backward to block i's (keyed by the fp32
-# gradient's address, tagged with the producing layer so a recycled address can never be mistaken for a live one)
+# bf16 shadows of residual-stream gradients handed from block i+1's backward to block i's: keyed by the fp32 gradient's
+# address and tagged with the producing layer.  The entry keeps a reference to the fp32 gradient itself, so (a) its address
+# cannot be recycled for another tensor while the entry lives and (b) autograd can never add a second consumer's gradient
+# into it IN PLACE (InputBuffer only does that to a uniquely owned buffer): with a second consumer of a block output the
+# summed gradient is a new tensor at a new address, the lookup misses and the consumer block casts it itself.
 _GRAD_SHADOW = {}
+
+
+class ContextGateFn(torch.autograd.Function):
+    """Identity at the entry of ContinuousTransformer for a TRAINABLE cross-attention context.  Its output is consumed by
+    this transformer's blocks and by nothing else, which is what lets them share one gradient accumulator (the first block
+    backward creates it, the others add into it from the GEMM epilogue and return None); its backward runs after every
+    block has contributed and hands the sum to whatever produced the context - where autograd adds the gradients of any
+    other consumer of the caller's tensor as usual."""
+
+    @staticmethod
+    def forward(ctx, context):
+        return context.view_as(context)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 def xdt_is_f32(ctx):
@@ -292,8 +311,6 @@ class TransformerBlockFn(torch.autograd.Function):
                 dst["acc"] = dctx                     # first contribution: this tensor is the gradient
             else:
                 dctx = None                           # accumulated in place
-        if dxb is not None:
-            _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb)
         gr = go.grads
         ctx.sv = None
         hook = getattr(blk, "_kalle_on_backward_done", None)
@@ -301,6 +318,8 @@ class TransformerBlockFn(torch.autograd.Function):
             hook(blk)
         xdt, cdt, gdt = ctx.dtypes
         dx = _like(dx, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
+        if dxb is not None:
+            _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb, dx)
         if dctx is not None and ctx.needs_input_grad[2]:
             dctx = dctx.view(ctx.ctx_shape).to(cdt)
         else:

@@ -237,8 +237,10 @@ class ContinuousTransformer(nn.Module):
         elif ctx is not None and ctx.dtype == torch.float32 and ctx.is_cuda:
             # trainable conditioning (to_cond_embed, dit.py:49-53): the fp32 tensor stays the autograd input of every layer;
             # its bf16 copy is made once and rides on it, and the layers share one gradient accumulator (functional.py)
-            ctx._kalle_bf16 = KF._to_bf16(ctx.detach().contiguous())
-            ctx._kalle_dctx = {}
+            gated = KF.ContextGateFn.apply(ctx) if ctx.requires_grad else ctx
+            gated._kalle_bf16 = KF._to_bf16(ctx.detach().contiguous())
+            gated._kalle_dctx = {}
+            kwargs = dict(kwargs, context=gated)
         for layer in self.layers:
             x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
             if return_info:

@@ -3,7 +3,8 @@
 This file is a from-scratch restatement (plain torch fp32 on the CPU, functional style over state dicts that use
 the reference's parameter names) of the algorithm in /root/reference/stable_audio_tools.  Each function cites the
 reference file:line it follows.  It is pinned against golden vectors produced by running the reference itself in
-the build container (tests/golden/make_golden.py -> tests/golden/*.npz; checked in tests/test_oracle_golden.py).
+the build container (tests/golden/make_golden.py, make_golden_r02.py -> tests/golden/*.npz; checked in
+tests/test_oracle_golden.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product path
 (kalle_audio_amd/*) never does: it runs hand-written HIP kernels and fails loudly without them.
@@ -11,6 +12,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 Parity status: PINNED for every function below by the committed fixtures, except `snake`-free statements marked
 otherwise.  Third-party arithmetic that enters: WNConv1d/WNConvTranspose1d == torch.nn.utils.weight_norm over
 Conv1d/ConvTranspose1d (descript-audio-codec `dac.nn.layers`, version unpinned in the reference).
+UNPINNED: `activation1d` (alias-free-torch is absent) and the label transform injected into `llasa_model_forward`
+(twj_utils is a dangling symlink in the reference); both are restated from published / in-tree definitions and say so.
 """
 import math
 
@@ -736,3 +739,79 @@ def llasa_forward(sd, cfg, batch, eps, std=0.5):
     tm, em = batch["target_mask"], batch["end_mask"]
     return {"audio_loss": (kl * tm).sum() / tm.sum(), "end_loss": (kl * em).sum() / em.sum(), "pre_mean": pred,
             "ground_truth_audio_latents": lat}
+
+
+# ---------------------------------------------------------------------------------------------- round 2: wrappers
+def llasa_model_forward(sd, cfg, batch, mean_stdev_fn):
+    """model.py:52-107 (the Stable-Audio-VAE `Llasa`): no sampling of the inputs; the head predicts mean || log-scale;
+    loss = KL(N(label_mean, 1.25 label_std) || N(pred_mean, exp(pred_log_scale))) summed over the latent dim / dim, masked
+    means.  `mean_stdev_fn` stands for twj_utils.get_mean_stdev_from_stableaudio2_latents, which the reference tree does not
+    contain (dangling symlink): [B, 2*lat, L] -> (mean, stdev) [B, lat, L]; parity of that callable is UNPINNED."""
+    m = _sub(sd, "base_model.model.")
+    text = m["embed_tokens.weight"][batch["input_ids"]]
+    lat = batch["audio_latents"]
+    audio = lat @ sd["audio_linear.weight"].T + sd["audio_linear.bias"]
+    x = audio * batch["audio_mask"].unsqueeze(-1) + text * batch["ids_mask"].unsqueeze(-1)
+    hidden = llama_model(m, cfg["llama"], x, batch["ids_mask"] + batch["audio_mask"])
+    h = hidden @ sd["distribution_linear.0.weight"].T + sd["distribution_linear.0.bias"]
+    pred = F.gelu(h) @ sd["distribution_linear.2.weight"].T + sd["distribution_linear.2.bias"]
+    mean1, std1 = mean_stdev_fn(batch["audio_distribution_l"].transpose(1, 2))
+    mean1, std1 = mean1.transpose(1, 2), std1.transpose(1, 2) * 1.25                   # model.py:85-87
+    mean2, logs2 = pred.chunk(2, dim=2)
+    std2 = torch.exp(logs2)
+    # KL(N(m1, s1) || N(m2, s2)) = log(s2 / s1) + (s1^2 + (m1 - m2)^2) / (2 s2^2) - 1/2   (torch.distributions, model.py:93-96)
+    kl = torch.log(std2 / std1) + (std1 ** 2 + (mean1 - mean2) ** 2) / (2 * std2 ** 2) - 0.5
+    kl = kl.sum(2) / lat.shape[-1]
+    tm, em = batch["target_mask"], batch["end_mask"]
+    return {"audio_loss": (kl * tm).sum() / tm.sum(), "end_loss": (kl * em).sum() / em.sum(), "pre_mean": mean2,
+            "pre_log_scale": logs2}
+
+
+def conditioning_inputs(cond, cross_ids, global_ids):
+    """models/diffusion.py:131-208 for cross-attention + global ids: cat over the sequence / channel dimension."""
+    out = {}
+    if cross_ids:
+        out["cross_attn_cond"] = torch.cat([cond[k][0] for k in cross_ids], 1)
+        out["cross_attn_cond_mask"] = torch.cat([cond[k][1] for k in cross_ids], 1)
+    if global_ids:
+        g = torch.cat([cond[k][0] for k in global_ids], -1)
+        out["global_embed"] = g.squeeze(1) if g.dim() == 3 else g
+    return out
+
+
+def training_step(sd_dit, cfg, sd_vae, vae_strides, reals, cond_inputs, t, noise, objective="v", padding_mask=None,
+                  pre_encoded=False, scale=1.0):
+    """DiffusionCondTrainingWrapper.training_step (training/diffusion.py:311-437) given the step's t and noise draws:
+    pretransform.encode under no_grad (340-351) or the pre-encoded / scale rule (353-356), the padding mask resized with
+    nearest interpolation to the latent length (349-351), noising + target (365-379), model (390), masked MSE (393-399)."""
+    x = reals
+    if not pre_encoded:
+        with torch.no_grad():
+            x = pretransform_encode(sd_vae, reals, vae_strides, True, scale)
+        if padding_mask is not None:
+            padding_mask = F.interpolate(padding_mask.unsqueeze(1).float(), size=x.shape[2], mode="nearest").squeeze(1).bool()
+    elif scale != 1.0:
+        x = x / scale
+    loss, out, xt, target = train_step_loss(sd_dit, cfg, x, noise, t, objective, padding_mask, **cond_inputs)
+    return loss
+
+
+def generate(sd_dit, cfg, sd_vae, vae_strides, noise, cond_inputs, steps, cfg_scale, objective, scale=1.0, neg=None,
+             return_latents=False):
+    """generate_diffusion_cond (inference/generation.py:90-250) after the seeded noise draw (138-142): rectified flow ->
+    sample_rf -> sample_discrete_euler (sampling.py:200-232, 24-45); v -> the in-tree DDIM sampler (sampling.py:47-86; the
+    reference itself routes v to third-party k-diffusion); then pretransform.decode (247)."""
+    kw = dict(cond_inputs)
+    if neg is not None:
+        kw.update(negative_cross_attn_cond=neg["cross_attn_cond"], negative_cross_attn_mask=neg["cross_attn_cond_mask"])
+    fn = lambda x_, t_: dit_forward(sd_dit, cfg, x_, t_, cfg_scale=cfg_scale, **kw)
+    lat = sample_euler(fn, noise, steps) if objective == "rectified_flow" else sample_ddim(fn, noise, steps, 0.0)
+    if return_latents:
+        return lat
+    return pretransform_decode(sd_vae, lat, vae_strides, True, scale, True)
+
+
+def export_int16(audio):
+    """infer_0723.py:292-293: "b d n -> d (b n)", divide by the peak, clamp, * 32767, int16"""
+    o = audio.permute(1, 0, 2).reshape(audio.shape[1], -1).float()
+    return (o / o.abs().max()).clamp(-1, 1).mul(32767).to(torch.int16)

@@ -57,11 +57,14 @@ def make_mask(name, shape, seed, p_keep=0.8):
 DIGEST_SAMPLES = 8
 
 
-def digest(arr):
-    """[l2 norm, sum, 8 fixed-position samples] of a gradient tensor"""
+def digest_index(size, n=DIGEST_SAMPLES):
+    return (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % size
+
+
+def digest(arr, n=DIGEST_SAMPLES):
+    """[l2 norm, sum, n fixed-position samples] of a gradient tensor (8 samples in the round-1 fixtures, 64 in the wide ones)"""
     a = np.asarray(arr, dtype=np.float64).reshape(-1)
-    idx = (np.arange(DIGEST_SAMPLES, dtype=np.int64) * 2654435761 + 12345) % a.size
-    return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[idx]]).astype(np.float64)
+    return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[digest_index(a.size, n)]]).astype(np.float64)
 
 
 # mel-VAE hyper-parameters used by the fixtures (the reference's own JSON for backup/flows.py is absent, SURVEY.md 8)
@@ -106,3 +109,68 @@ def llasa_batch(lc, seed, B=3, L=40):
     return dict(input_ids=ids, audio_latents=make_input("llasa_lat", (B, L, lat), seed),
                 audio_distribution_l=make_input("llasa_lbl", (B, L, lat), seed), ids_mask=ids_mask,
                 audio_mask=audio_mask, target_mask=target_mask, end_mask=end_mask)
+
+
+# round-2 fixtures --------------------------------------------------------------------------------------------------------
+# bench-width TransformerBlock (D = 1536, 24 heads, context 768 = 12 kv heads, 126 tokens, 130 context tokens)
+WIDE_BLOCK = dict(D=1536, DC=768, N=126, S=130, B=1)
+
+# Llasa at 4 heads / 2 kv heads, sequences of ~300 with ragged right padding (30 s clips of configs/twj_0828.yaml are
+# 375 frames + text)
+LLASA_WIDE_CONFIG = dict(
+    latent_dim=32, tokenizer_len=310,
+    llama=dict(vocab_size=300, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+               num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=1024,
+               rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                 original_max_position_embeddings=64),
+               tie_word_embeddings=True, attention_bias=False, mlp_bias=False, hidden_act="silu"))
+
+
+def llasa_batch_long(lc, seed, B=3, L=300, label_mult=1):
+    """llasa_batch with the text / audio lengths scaled to L (sample 0 unpadded, the others ragged)"""
+    rng = np.random.Generator(np.random.PCG64(_seed_for("llasa_batch_long", seed)))
+    lat = lc["latent_dim"]
+    ids = rng.integers(0, lc["tokenizer_len"], size=(B, L)).astype(np.int64)
+    ids_mask = np.zeros((B, L), np.float32)
+    audio_mask = np.zeros((B, L), np.float32)
+    target_mask = np.zeros((B, L), np.float32)
+    end_mask = np.zeros((B, L), np.float32)
+    for b in range(B):
+        nt = int(rng.integers(4, max(6, min(40, L // 4))))
+        na = int(rng.integers(L // 3, L - nt - 1)) if b else L - nt
+        ids_mask[b, :nt] = 1
+        audio_mask[b, nt:nt + na] = 1
+        target_mask[b, nt - 1:nt + na - 1] = 1
+        end_mask[b, nt + na - 1] = 1
+    return dict(input_ids=ids, audio_latents=make_input("llasa_lat", (B, L, lat), seed),
+                audio_distribution_l=make_input("llasa_lbl", (B, L, lat * label_mult), seed), ids_mask=ids_mask,
+                audio_mask=audio_mask, target_mask=target_mask, end_mask=end_mask)
+
+
+def default_mean_stdev(latents):
+    """stand-in for the reference's MISSING twj_utils.get_mean_stdev_from_stableaudio2_latents (model.py:7,84; the file is a
+    dangling symlink): latents [B, 2*lat, L] = mean || scale of the Oobleck encoder; stdev = softplus(scale) + 1e-4 as
+    stable_audio_tools/models/bottleneck.py:51-54 derives it from the same tensor.  Parity of THIS callable is unpinned;
+    everything around it (model.py:84-100) is pinned with it injected on both sides.  torch in, torch out."""
+    import torch
+    mean, scale = latents.chunk(2, dim=1)
+    return mean, torch.nn.functional.softplus(scale) + 1e-4
+
+
+# tiny Oobleck autoencoder shared by the end-to-end fixtures (same layout as make_golden.py's oobleck_vae_snake)
+def oobleck_cfg(snake=True):
+    return {
+        "model_type": "autoencoder", "sample_rate": 16000, "sample_size": 4096, "audio_channels": 2,
+        "model": {
+            "encoder": {"type": "oobleck", "config": {"in_channels": 2, "channels": 8, "c_mults": [1, 2, 4],
+                                                     "strides": [2, 4, 5], "latent_dim": 8, "use_snake": snake}},
+            "decoder": {"type": "oobleck", "config": {"out_channels": 2, "channels": 8, "c_mults": [1, 2, 4],
+                                                     "strides": [2, 4, 5], "latent_dim": 4, "use_snake": snake,
+                                                     "final_tanh": snake}},
+            "bottleneck": {"type": "vae"},
+            "latent_dim": 4, "downsampling_ratio": 40, "io_channels": 2,
+        },
+    }
+
+
+E2E = dict(D=128, DC=64, G=32, S=9, T=125, B=2, seed=777, steps=4, cfg_scale=3.0)

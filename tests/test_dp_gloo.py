@@ -111,3 +111,26 @@ def test_cosine_schedule_and_checkpoint_discovery(tmp_path):
     (tmp_path / "epoch_3_step_1200.pt").write_bytes(b"x")
     path, ep, st = config.latest_checkpoint(str(tmp_path))
     assert (ep, st) == (3, 1200) and path.endswith("epoch_3_step_1200.pt")
+
+
+def test_trainer_lr_matches_transformers_cosine_schedule(monkeypatch):
+    """The k-th optimizer step must use the LR that optimizer.step(); scheduler.step() (train_offline.py:247-248) would:
+    transformers.get_cosine_schedule_with_warmup's lr_lambda(k - 1), also after a resume offset (examples/train_offline_hip.py)
+    and a few steps past total_steps (same values as the library there too)."""
+    from transformers import get_cosine_schedule_with_warmup
+    from kalle_audio_amd import engine, ops
+    monkeypatch.setattr(ops, "adam_step", lambda *a, **k: None)       # the fused Adam launch needs the GPU; the LR logic does not
+    warm, total, base, step0 = 5, 40, 3e-4, 7
+    for offset in (0, step0):
+        model = torch.nn.Linear(8, 8)
+        tr = engine.DataParallelTrainer(model, lr=base, optimizer="AdamW",
+                                        lr_schedule=lambda s, o=offset: engine.cosine_with_warmup(s + o, warm, total))
+        ref_opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=base)
+        ref = get_cosine_schedule_with_warmup(ref_opt, warm, total)
+        for _ in range(offset):
+            ref_opt.step(); ref.step()
+        for k in range(total + 10 - offset):
+            want = ref_opt.param_groups[0]["lr"]
+            tr.optimizer_step()
+            assert abs(tr.last_lr - want) <= 1e-12 + 1e-9 * want, (offset, k, tr.last_lr, want)
+            ref_opt.step(); ref.step()

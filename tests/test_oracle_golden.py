@@ -251,3 +251,214 @@ def test_llasa():
     close(out["ground_truth_audio_latents"], f["sampled"])
     (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
     check_digests(f, sd, tol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ round-2 fixtures
+def check_digests_n(f, sd, n, prefix="", tol=5e-5, strip=""):
+    cnt = 0
+    for k in f.files:
+        if k.startswith(prefix + "digest/"):
+            name = k[len(prefix) + 7:]
+            key = name[len(strip):] if strip and name.startswith(strip) else name
+            got = gu.digest(sd[key].grad.numpy(), n)
+            ref = f[k]
+            scale = max(abs(ref[0]), 1e-12)
+            assert np.all(np.abs(got - ref) <= tol * scale + 1e-7), (name, got[:3], ref[:3])
+            cnt += 1
+    assert cnt > 0
+
+
+@pytest.mark.parametrize("name,ada,seed", [("block_wide_plain", False, 50), ("block_wide_adaln", True, 51)])
+def test_transformer_block_bench_width(name, ada, seed):
+    """one TransformerBlock at the benchmark's width (D = 1536, 24 heads, 12 kv heads, 126 tokens, 130 context tokens);
+    outputs are stored as fp16 (5e-4), parameter-gradient digests (64 samples) in fp64"""
+    f = fx(name)
+    w = gu.WIDE_BLOCK
+    Dw, DCw, Nw, Sw, Bw = w["D"], w["DC"], w["N"], w["S"], w["B"]
+    x = T(gu.make_input("x", (Bw, Nw, Dw), seed), True)
+    ctx = T(gu.make_input("ctx", (Bw, Sw, DCw), seed), True)
+    dy = T(gu.make_input("dy", (Bw, Nw, Dw), seed))
+    sd = state(ko.block_shapes(Dw, dim_context=DCw, global_cond_dim=Dw if ada else None), seed)
+    gc = T(gu.make_input("g", (Bw, Dw), seed), True) if ada else None
+    y = ko.transformer_block(sd, x, context=ctx, global_cond=gc, rotary=ko.rotary_freqs(Nw))
+    y.backward(dy)
+    close(y, f["y"].astype(np.float32), 1e-3); close(x.grad, f["dx"].astype(np.float32), 1e-3)
+    close(ctx.grad, f["dctx"].astype(np.float32), 1e-3)
+    if ada:
+        close(gc.grad, f["dg"].astype(np.float32), 1e-3)
+    check_digests_n(f, sd, 64)
+
+
+def test_dit_long_sequence():
+    """375 latent frames + 1 prepended token, 130 context tokens: three key blocks of the attention kernel's 128"""
+    f = fx("dit_long")
+    Bl, Nl, Sl, seed = 2, 375, 130, 52
+    cfg = dict(embed_dim=D, depth=2, num_heads=2, global_cond_type="prepend")
+    shapes = ko.dit_shapes(CIO, D, 2, cond_token_dim=DC, global_cond_dim=GD, project_cond_tokens=False)
+    sd = state(shapes, seed)
+    lat = T(gu.make_input("lat", (Bl, CIO, Nl), seed))
+    noise = T(gu.make_input("noise", (Bl, CIO, Nl), seed))
+    tt = T(np.array([0.2, 0.65], dtype=np.float32))
+    ctx = T(gu.make_input("ctx", (Bl, Sl, DC), seed))
+    gl = T(gu.make_input("glob", (Bl, GD), seed))
+    pm = T(gu.make_mask("pm", (Bl, Nl), seed, 0.7))
+    loss, out, xt, tgt = ko.train_step_loss(sd, cfg, lat, noise, tt, "v", cross_attn_cond=ctx, global_embed=gl)
+    loss.backward()
+    close(out, f["output"], 1e-5)
+    assert abs(loss.item() - f["loss"].item()) < 1e-5 * abs(loss.item())
+    lm = ko.mse_loss(out, tgt, pm)
+    assert abs(lm.item() - f["loss_masked"].item()) < 1e-5 * abs(lm.item())
+    check_digests_n(f, sd, 16)
+    with torch.no_grad():
+        close(ko.dit_forward(sd, cfg, xt, tt, cross_attn_cond=ctx, global_embed=gl, cfg_scale=2.5), f["output_cfg"], 1e-5)
+
+
+def _llasa_shapes(key, file="state_dict_keys.json"):
+    import json
+    inv = json.load(open(os.path.join(G, file)))[key]
+    return [(k, tuple(v)) for k, v in inv.items() if k != "base_model.lm_head.weight"]
+
+
+def llasa_wide_shapes():
+    """same parameter names as the round-1 Llasa inventory, at the wide fixture's sizes"""
+    lc = gu.LLASA_WIDE_CONFIG
+    ll, lat = lc["llama"], lc["latent_dim"]
+    Dh, I, H, Hkv = ll["hidden_size"], ll["intermediate_size"], ll["num_attention_heads"], ll["num_key_value_heads"]
+    out = []
+    for k, v in _llasa_shapes("llasa"):
+        if k.endswith("embed_tokens.weight"):
+            v = (lc["tokenizer_len"], Dh)
+        elif k.endswith("q_proj.weight") or k.endswith("o_proj.weight"):
+            v = (H * 64, Dh) if k.endswith("q_proj.weight") else (Dh, H * 64)
+        elif k.endswith("k_proj.weight") or k.endswith("v_proj.weight"):
+            v = (Hkv * 64, Dh)
+        elif k.endswith("gate_proj.weight") or k.endswith("up_proj.weight"):
+            v = (I, Dh)
+        elif k.endswith("down_proj.weight"):
+            v = (Dh, I)
+        elif k.endswith("layernorm.weight") or k.endswith("model.norm.weight"):
+            v = (Dh,)
+        elif k == "audio_linear.weight":
+            v = (Dh, lat)
+        elif k == "audio_linear.bias":
+            v = (Dh,)
+        elif k == "distribution_linear.0.weight":
+            v = (lat, Dh)
+        elif k == "distribution_linear.2.weight":
+            v = (lat, lat)
+        elif k.startswith("distribution_linear"):
+            v = (lat,)
+        out.append((k, v))
+    return out
+
+
+def test_llasa_wide():
+    """model_sigmaVAE.Llasa at 4 heads / 2 kv heads, ragged sequences of 300 (llama3 rope scaling active)"""
+    f = fx("llasa_wide")
+    lc = gu.LLASA_WIDE_CONFIG
+    sd = state(llasa_wide_shapes(), 53)
+    batch = {k: T(v) for k, v in gu.llasa_batch_long(lc, 53).items()}
+    eps = T(gu.make_input("llasa_eps", tuple(batch["audio_latents"].shape), 53))
+    out = ko.llasa_forward(sd, lc, batch, eps)
+    close(out["audio_loss"], f["audio_loss"], 1e-5)
+    close(out["end_loss"], f["end_loss"], 1e-5)
+    close(out["pre_mean"], f["pre_mean"].astype(np.float32), 1e-3)
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    check_digests_n(f, sd, 16, tol=1e-4)
+    for k in ("audio_linear.weight", "base_model.model.norm.weight"):
+        close(sd[k].grad, f["grad/" + k], 2e-5)
+
+
+def test_model_llasa_two_gaussian_kl():
+    """model.py's Llasa: head of 2 * latent_dim, KL(N(label_mean, 1.25 label_std) || N(pred_mean, exp(pred_log_scale)))"""
+    f = fx("model_llasa")
+    lc = gu.LLASA_CONFIG
+    sd = state(_llasa_shapes("model_llasa", "state_dict_keys_r02.json"), 54)
+    batch = {k: T(v) for k, v in gu.llasa_batch_long(lc, 54, B=3, L=48, label_mult=2).items()}
+    out = ko.llasa_model_forward(sd, lc, batch, gu.default_mean_stdev)
+    close(out["audio_loss"], f["audio_loss"], 1e-5)
+    close(out["end_loss"], f["end_loss"], 1e-5)
+    close(out["pre_mean"], f["pre_mean"], 1e-5)
+    close(out["pre_log_scale"], f["pre_log_scale"], 1e-5)
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    check_digests_n(f, sd, 16, tol=1e-4)
+    for k in ("audio_linear.weight", "distribution_linear.2.bias", "distribution_linear.0.weight", "base_model.model.norm.weight"):
+        close(sd[k].grad, f["grad/" + k], 2e-5)
+
+
+def e2e_states(io_channels, seed, grad=False):
+    """the DiT of make_golden_r02._cond_model is seeded under DiTWrapper's names ("model." + DiffusionTransformer name)"""
+    e = gu.E2E
+    shapes = ko.dit_shapes(io_channels, e["D"], 2, cond_token_dim=e["DC"], global_cond_dim=e["G"], project_cond_tokens=False)
+    st = gu.make_state([("model." + k, v) for k, v in shapes], seed)
+    sd_dit = {k[len("model."):]: T(v, grad) for k, v in st.items()}
+    vshapes = (ko.oobleck_encoder_shapes(2, 8, 8, [1, 2, 4], [2, 4, 5], True, "encoder.") +
+               ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], True, "decoder."))
+    return sd_dit, state(vshapes, 23, False)
+
+
+def e2e_cond(seed):
+    e = gu.E2E
+    ctx = T(gu.make_input("ctx", (e["B"], e["S"], e["DC"]), seed))
+    cm = T(gu.make_mask("cm", (e["B"], e["S"]), seed))
+    gl = T(gu.make_input("glob", (e["B"], e["G"]), seed))
+    return ctx, cm, gl
+
+
+def test_generate_end_to_end():
+    """seed -> noise -> 4-step CFG sampler -> Oobleck decode -> int16, against generate_diffusion_cond itself"""
+    f = fx("generate_e2e")
+    e = gu.E2E
+    cfg = dict(embed_dim=e["D"], depth=2, num_heads=2, global_cond_type="prepend")
+    ctx, cm, gl = e2e_cond(60)
+    cond = {"prompt": (ctx, cm), "g": (gl, None)}
+    ci = ko.conditioning_inputs(cond, ["prompt"], ["g"])
+    neg = ko.conditioning_inputs({"prompt": (ctx.flip(0), cm.flip(0)), "g": (gl, None)}, ["prompt"], ["g"])
+    torch.manual_seed(e["seed"])                                   # generation.py:138-142
+    noise = torch.randn([e["B"], 4, e["T"]])
+    with torch.no_grad():
+        sd_dit, sd_vae = e2e_states(4, 60)
+        lat = ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "rectified_flow", 0.8,
+                          return_latents=True)
+        close(lat, f["rf/latents"], 2e-5)
+        audio = ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "rectified_flow", 0.8)
+        close(audio, f["rf/audio"], 5e-5)
+        i16 = ko.export_int16(audio).numpy().astype(np.int32)
+        assert np.abs(i16 - f["rf/int16"].astype(np.int32)).max() <= 2            # +-1 LSB of rounding noise, peak included
+        close(ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "rectified_flow", 0.8, neg=neg),
+              f["rf_neg/audio"], 5e-5)
+        sd_dit, _ = e2e_states(4, 61)
+        close(ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "v", 0.8, return_latents=True),
+              f["v/latents"], 2e-5)
+        close(ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "v", 0.8), f["v/audio"], 5e-5)
+
+
+@pytest.mark.parametrize("tag,objective,pre,seed", [("v_uniform", "v", False, 62), ("rf_logit", "rectified_flow", False, 63),
+                                                    ("v_pre", "v", True, 64)])
+def test_training_step_wrapper(tag, objective, pre, seed):
+    """DiffusionCondTrainingWrapper.training_step run by the reference class; the scrambled Sobol draw is torch's own
+    engine seeded from the global generator, so it must reproduce here bit for bit"""
+    f = fx("training_step")
+    e = gu.E2E
+    Bt = e["B"]
+    cfg = dict(embed_dim=e["D"], depth=2, num_heads=2, global_cond_type="prepend")
+    sd_dit, sd_vae = e2e_states(8, seed, grad=True)
+    ctx, cm, gl = e2e_cond(seed)
+    ci = ko.conditioning_inputs({"prompt": (ctx, cm), "g": (gl, None)}, ["prompt"], ["g"])
+    if objective == "v":
+        torch.manual_seed(1000 + seed)
+        t = torch.quasirandom.SobolEngine(1, scramble=True).draw(Bt)[:, 0]     # training/diffusion.py:257, 360
+        assert torch.equal(t, T(f[f"{tag}/t"]))
+    else:
+        t = torch.sigmoid(T(f[f"{tag}/t_logit"]))                               # training/diffusion.py:362
+    noise = T(f[f"{tag}/noise"])
+    if pre:
+        reals = T(gu.make_input("lat8", (Bt, 8, e["T"]), seed))
+        pm = T(gu.make_mask("pm", (Bt, e["T"]), seed, 0.75))
+    else:
+        reals = T(gu.make_input("wav", (Bt, 2, 40 * e["T"]), seed, 0.5))
+        pm = T(gu.make_mask("pm", (Bt, e["T"]), seed, 0.75)).repeat_interleave(40, dim=1)
+    loss = ko.training_step(sd_dit, cfg, sd_vae, [2, 4, 5], reals, ci, t, noise, objective, pm, pre_encoded=pre, scale=0.8)
+    loss.backward()
+    assert abs(loss.item() - f[f"{tag}/loss"].item()) < 2e-5 * abs(loss.item()), (loss.item(), f[f"{tag}/loss"].item())
+    check_digests_n(f, sd_dit, 16, prefix=f"{tag}/", tol=1e-4, strip="model.")
