@@ -156,6 +156,7 @@ def main():
     fence()
     timer = None if (args.no_kernel_timer or rank != 0) else []
     ops.KERNEL_TIMER = timer
+    trainer.comm_timing = []          # events around the all-reduce waits of the timed steps (exposed communication)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -167,6 +168,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss_v = loss.item()
+    comm = trainer.comm_summary()     # RCCL rank count, buckets per step, exposed (non-overlapped) all-reduce time
+    trainer.comm_timing = None
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -185,6 +188,7 @@ def main():
                        "global_cond_type": CFG["global_cond_type"], "loss": loss_v},
             "algorithmic_tflops_per_gpu": 3 * fwd * args.batch * args.steps / dt / 1e12,
             "mfma_roofline_frac_step": 3 * fwd * args.batch * args.steps / dt / 1e12 / PEAK_BF16_TFLOPS,
+            "comm": comm,
         }
         if timer:
             agg = {}
@@ -198,7 +202,9 @@ def main():
             name, (fl, sec, n, ab) = dom
             ach = fl / sec / 1e12
             traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            tj = os.path.join(ROOT, "profiles", "traffic_r02.json")
+            if not os.path.exists(tj):
+                tj = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tj):
                 traffic = json.load(open(tj)).get(name)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_TFLOPS,

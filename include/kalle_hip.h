@@ -171,6 +171,18 @@ int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_stride, int64
                     int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int rows, int cols,
                     int accumulate, void* stream);
 
+/* Chunked VAE encode / decode (AudioAutoencoder.encode_audio / decode_audio, autoencoders.py:429-560) as a batched pipeline:
+ * every chunk rides on the batch axis of ONE encoder / decoder pass; this call is the gather in front of it and the paste
+ * of the trimmed chunk centres behind it.  For segment s < nseg (<= KALLE_MAX_SEGMENTS), batch item b, row (channel) c:
+ *   dst[s*dst_seg_stride + b*dst_batch_stride + c*dst_ld + dst_off[s] + j] =
+ *   src[s*src_seg_stride + b*src_batch_stride + c*src_ld + src_off[s] + j]          for j < len[s]
+ * offsets / strides in elements; src_off / dst_off / len are HOST arrays (copied into the launch); destinations of
+ * different segments must not overlap; src and dst have the same dtype (fp32 or bf16). */
+#define KALLE_MAX_SEGMENTS 64
+int kalle_segment_copy(const void* src, void* dst, int dtype, int nseg, const int64_t* src_off, const int64_t* dst_off,
+                       const int* len, int nbatch, int rows, int64_t src_seg_stride, int64_t src_batch_stride,
+                       int64_t src_ld, int64_t dst_seg_stride, int64_t dst_batch_stride, int64_t dst_ld, void* stream);
+
 /* dtype conversion fp32 <-> bf16 (n elements, n % 8 == 0 not required) */
 int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 
@@ -352,6 +364,18 @@ int kalle_gauss_kl_fwd(const float* pred, const float* label, const float* mask_
 int kalle_gauss_kl_bwd(const float* pred, const float* label, const float* mask_a, const float* mask_b,
                        const float* sums4, const float* grad_a, const float* grad_b, float* dpred, float std,
                        int64_t rows, int dim, void* stream);
+
+/* masked two-Gaussian KL of the Stable-Audio-VAE task model (model.py:84-100):
+ *   kl[r] = sum_c KL( N(m1, s1) || N(m2, exp(l2)) ) / dim,   m2 | l2 = the halves of pred [rows][2 dim] (model.py:89-90)
+ * label_mode 0: label_mean / label_std [rows][dim] hold the label statistics (the transform of model.py:84 already applied
+ * by the caller); label_mode 1: label_mean is the raw label [rows][2 dim] = mean | scale and std = softplus(scale) + 1e-4
+ * (label_std unused).  std is multiplied by std_mult (1.25, model.py:87).  sums4 / grad_a / grad_b as kalle_gauss_kl_*;
+ * dpred [rows][2 dim]. */
+int kalle_gauss_kl2_fwd(const float* pred, const float* label_mean, const float* label_std, int label_mode, float std_mult,
+                        const float* mask_a, const float* mask_b, float* sums4, int64_t rows, int dim, void* stream);
+int kalle_gauss_kl2_bwd(const float* pred, const float* label_mean, const float* label_std, int label_mode, float std_mult,
+                        const float* mask_a, const float* mask_b, const float* sums4, const float* grad_a,
+                        const float* grad_b, float* dpred, int64_t rows, int dim, void* stream);
 
 /* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
  * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)

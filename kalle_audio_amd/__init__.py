@@ -20,8 +20,9 @@ def install():
                 "training.diffusion", "training.losses", "training.losses.losses", "training.utils", "inference",
                 "inference.sampling", "inference.generation"):
         sys.modules["stable_audio_tools." + sub] = importlib.import_module(f"{__name__}.stable_audio_tools.{sub}")
-    # the reference's top-level modules on the path: the task model (train_offline.py:19 `from model_sigmaVAE import
-    # Llasa`) and the mel-VAE (infer_0828_sigma.py:18 `from flows import BigVGANFlowVAE`)
+    # the reference's top-level modules on the path: the task models (train_offline.py:19 `from model_sigmaVAE import
+    # Llasa`, train.py:24 `from model import Llasa`) and the mel-VAE (infer_0828_sigma.py:18 `from flows import BigVGANFlowVAE`)
     sys.modules["model_sigmaVAE"] = importlib.import_module(__name__ + ".model_sigmaVAE")
+    sys.modules["model"] = importlib.import_module(__name__ + ".model")          # train.py:24 `from model import Llasa`
     sys.modules["flows"] = importlib.import_module(__name__ + ".flows")
     return pkg

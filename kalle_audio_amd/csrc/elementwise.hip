@@ -199,6 +199,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
     }
 }
 
+// ---- segment copy: the gather / paste of chunked VAE encode / decode (autoencoders.py:429-560) in ONE launch --------------
+// For segment s, batch item b, channel c:  dst[s*dst_ss + b*dst_bs + c*dst_ld + dst_off[s] + j] = src[s*src_ss + b*src_bs +
+// c*src_ld + src_off[s] + j], j < len[s].  Gather: src_ss = 0 (every chunk reads the same signal), dst_ss = one chunk batch;
+// paste: the other way round, segments trimmed so that their destinations are disjoint.  Same element type both sides.
+struct SegTable {
+    int64_t src_off[KALLE_MAX_SEGMENTS], dst_off[KALLE_MAX_SEGMENTS];
+    int len[KALLE_MAX_SEGMENTS];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void segment_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, SegTable tab,
+                                                           int nbatch, int rows, int64_t src_ss, int64_t src_bs,
+                                                           int64_t src_ld, int64_t dst_ss, int64_t dst_bs, int64_t dst_ld) {
+    const int row = blockIdx.y;                 // (segment, batch, channel)
+    const int s = row / (nbatch * rows);
+    const int br = row - s * nbatch * rows;
+    const int b = br / rows, c = br - b * rows;
+    const T* sp = src + s * src_ss + b * src_bs + c * src_ld + tab.src_off[s];
+    T* dp = dst + s * dst_ss + b * dst_bs + c * dst_ld + tab.dst_off[s];
+    const int n = tab.len[s];
+    constexpr int V = 16 / sizeof(T);
+    const bool vec = (((uintptr_t)sp | (uintptr_t)dp) & 15) == 0;
+    if (vec) {
+        const int nv = n / V;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x)
+            reinterpret_cast<i32x4*>(dp)[i] = reinterpret_cast<const i32x4*>(sp)[i];
+        for (int i = nv * V + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+    }
+}
+
 // ---- strided row copy with dtype conversion: out[b][r][:] = in[b][r][:]  -------------------------
 template <bool IF32, bool OF32>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
@@ -505,3 +536,33 @@ extern "C" void kalle_set_last_error(const char* what) {
 extern "C" const char* kalle_last_error(void) { return g_last_error; }
 extern "C" int kalle_abi_version(void) { return 1; }
 extern "C" const char* kalle_target_arch(void) { return "gfx950"; }
+
+extern "C" int kalle_segment_copy(const void* src, void* dst, int dtype, int nseg, const int64_t* src_off,
+                                  const int64_t* dst_off, const int* len, int nbatch, int rows, int64_t src_seg_stride,
+                                  int64_t src_batch_stride, int64_t src_ld, int64_t dst_seg_stride,
+                                  int64_t dst_batch_stride, int64_t dst_ld, void* stream) {
+    if (!src || !dst || !src_off || !dst_off || !len || nseg <= 0 || nseg > KALLE_MAX_SEGMENTS || nbatch <= 0 || rows <= 0)
+        return KALLE_ERR_ARG;
+    if (dtype != KALLE_F32 && dtype != KALLE_BF16) return KALLE_ERR_ARG;
+    if ((int64_t)nseg * nbatch * rows > 65535) return KALLE_ERR_ARG;
+    SegTable tab{};
+    int maxlen = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (len[i] < 0 || src_off[i] < 0 || dst_off[i] < 0) return KALLE_ERR_ARG;
+        tab.src_off[i] = src_off[i]; tab.dst_off[i] = dst_off[i]; tab.len[i] = len[i];
+        maxlen = len[i] > maxlen ? len[i] : maxlen;
+    }
+    if (maxlen == 0) return KALLE_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per = dtype == KALLE_F32 ? 4 : 8;
+    int gx = (maxlen / per + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    dim3 grid(gx, nseg * nbatch * rows), block(256);
+    if (dtype == KALLE_F32)
+        KALLE_LAUNCH(segment_copy_kernel<float>, grid, block, 0, st, static_cast<const float*>(src), static_cast<float*>(dst), tab,
+                     nbatch, rows, src_seg_stride, src_batch_stride, src_ld, dst_seg_stride, dst_batch_stride, dst_ld);
+    else
+        KALLE_LAUNCH(segment_copy_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(src), static_cast<bf16_t*>(dst),
+                     tab, nbatch, rows, src_seg_stride, src_batch_stride, src_ld, dst_seg_stride, dst_batch_stride, dst_ld);
+    return kalle_check_launch();
+}

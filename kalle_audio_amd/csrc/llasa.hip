@@ -301,6 +301,77 @@ __global__ __launch_bounds__(256) void gauss_kl_bwd_kernel(const float* __restri
     }
 }
 
+// ---- two-Gaussian KL of model.py:84-100 --------------------------------------------------------------------------------
+// KL( N(m1, s1) || N(m2, s2) ) = log(s2 / s1) + (s1^2 + (m1 - m2)^2) / (2 s2^2) - 1/2 per latent element, with
+// m2 | log s2 = the two halves of the head's output row [2 dim]; summed over the latent dim / dim; two masked sums over rows.
+// Label statistics: MODE 0 - explicit mean / std rows [dim] (a caller-supplied transform already applied);
+//                   MODE 1 - one row [2 dim] = mean | scale of the Oobleck encoder, std = softplus(scale) + 1e-4
+//                            (stable_audio_tools/models/bottleneck.py:51-54 on the same tensor); both times std_mult (1.25).
+template <int MODE>
+__device__ __forceinline__ void kl2_label(const float* __restrict__ lmean, const float* __restrict__ lstd, int64_t r, int c,
+                                          int d, float std_mult, float& m1, float& s1) {
+    if constexpr (MODE == 0) {
+        m1 = lmean[r * d + c];
+        s1 = lstd[r * d + c] * std_mult;
+    } else {
+        m1 = lmean[r * 2 * d + c];
+        const float sc = lmean[r * 2 * d + d + c];
+        s1 = ((sc > 20.f ? sc : log1pf(expf(sc))) + 1e-4f) * std_mult;      // F.softplus (threshold 20)
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gauss_kl2_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ lmean,
+                                                            const float* __restrict__ lstd, const float* __restrict__ ma,
+                                                            const float* __restrict__ mb, float* __restrict__ sums,
+                                                            float std_mult, int64_t rows, int d) {
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float inv_d = 1.f / (float)d;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            float m1, s1;
+            kl2_label<MODE>(lmean, lstd, r, c, d, std_mult, m1, s1);
+            const float m2 = pred[r * 2 * d + c], l2 = pred[r * 2 * d + d + c];
+            const float dm = m1 - m2;
+            s += l2 - logf(s1) + 0.5f * (s1 * s1 + dm * dm) * expf(-2.f * l2) - 0.5f;
+        }
+        s = wave_sum(s) * inv_d;
+        const float a = ma[r], b = mb[r];
+        acc[0] += s * a; acc[1] += a; acc[2] += s * b; acc[3] += b;
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                       red[3][threadIdx.x]);
+}
+
+// d kl / d m2 = (m2 - m1) / s2^2 ;  d kl / d log s2 = 1 - (s1^2 + (m1 - m2)^2) / s2^2 ; times the row weight / dim
+template <int MODE>
+__global__ __launch_bounds__(256) void gauss_kl2_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ lmean,
+                                                            const float* __restrict__ lstd, const float* __restrict__ ma,
+                                                            const float* __restrict__ mb, const float* __restrict__ sums,
+                                                            const float* __restrict__ ga, const float* __restrict__ gb,
+                                                            float* __restrict__ dpred, float std_mult, int64_t rows, int d) {
+    const float wa = ga[0] / sums[1], wb = gb[0] / sums[3];
+    const float inv_d = 1.f / (float)d;
+    const int64_t total = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        float m1, s1;
+        kl2_label<MODE>(lmean, lstd, r, c, d, std_mult, m1, s1);
+        const float m2 = pred[r * 2 * d + c], l2 = pred[r * 2 * d + d + c];
+        const float w = (wa * ma[r] + wb * mb[r]) * inv_d, e = expf(-2.f * l2), dm = m2 - m1;
+        dpred[r * 2 * d + c] = w * dm * e;
+        dpred[r * 2 * d + d + c] = w * (1.f - (s1 * s1 + dm * dm) * e);
+    }
+}
+
 }  // namespace
 
 extern "C" int kalle_axpby(const float* x, const float* y, float* out, float a, float b, int64_t n, void* stream) {
@@ -434,5 +505,34 @@ extern "C" int kalle_gauss_kl_bwd(const float* pred, const float* label, const f
     const float coef = 1.f / (2.f * std * std * (float)dim);
     KALLE_LAUNCH(gauss_kl_bwd_kernel, dim3(grid_for(rows * dim, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pred,
                  label, mask_a, mask_b, sums4, grad_a, grad_b, dpred, coef, rows, dim);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_gauss_kl2_fwd(const float* pred, const float* label_mean, const float* label_std, int label_mode,
+                                   float std_mult, const float* mask_a, const float* mask_b, float* sums4, int64_t rows,
+                                   int dim, void* stream) {
+    if (!pred || !label_mean || !mask_a || !mask_b || !sums4 || rows <= 0 || dim <= 0 || !(std_mult > 0.f)) return KALLE_ERR_ARG;
+    if (label_mode != 0 && label_mode != 1) return KALLE_ERR_ARG;
+    if (label_mode == 0 && !label_std) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for((rows + 3) / 4, 1)), block(256);
+    if (label_mode == 0) KALLE_LAUNCH(gauss_kl2_fwd_kernel<0>, grid, block, 0, st, pred, label_mean, label_std, mask_a, mask_b, sums4, std_mult, rows, dim);
+    else KALLE_LAUNCH(gauss_kl2_fwd_kernel<1>, grid, block, 0, st, pred, label_mean, label_std, mask_a, mask_b, sums4, std_mult, rows, dim);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_gauss_kl2_bwd(const float* pred, const float* label_mean, const float* label_std, int label_mode,
+                                   float std_mult, const float* mask_a, const float* mask_b, const float* sums4,
+                                   const float* grad_a, const float* grad_b, float* dpred, int64_t rows, int dim,
+                                   void* stream) {
+    if (!pred || !label_mean || !mask_a || !mask_b || !sums4 || !grad_a || !grad_b || !dpred || rows <= 0 || dim <= 0 ||
+        !(std_mult > 0.f))
+        return KALLE_ERR_ARG;
+    if (label_mode != 0 && label_mode != 1) return KALLE_ERR_ARG;
+    if (label_mode == 0 && !label_std) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(rows * dim, 256)), block(256);
+    if (label_mode == 0) KALLE_LAUNCH(gauss_kl2_bwd_kernel<0>, grid, block, 0, st, pred, label_mean, label_std, mask_a, mask_b, sums4, grad_a, grad_b, dpred, std_mult, rows, dim);
+    else KALLE_LAUNCH(gauss_kl2_bwd_kernel<1>, grid, block, 0, st, pred, label_mean, label_std, mask_a, mask_b, sums4, grad_a, grad_b, dpred, std_mult, rows, dim);
     return kalle_check_launch();
 }

@@ -178,6 +178,7 @@ class DataParallelTrainer:
         self.step_count = 0
         self.micro = 0
         self.last_lr = lr
+        self.comm_timing = None            # set to a list to collect (start, end, buckets) events of the all-reduce waits
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         device = named[0][1].device
         # bucket key: the owning TransformerBlock's module path, or "_rest"
@@ -231,11 +232,31 @@ class DataParallelTrainer:
     def _finish_comm(self):
         if self._boundary():
             self._allreduce(self.flat.bucket_grad("_rest")) if "_rest" in self.flat.bucket_range else None
+        timed = self.comm_timing is not None and self._pending and self.flat.grad.is_cuda
+        if timed:
+            # exposed (not overlapped) all-reduce time = how long the compute stream sits in the waits below: nothing is
+            # launched on it between the two events
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for work, low, dst in self._pending:
             work.wait()
             if low is not None:
                 ops.copy_rows(low, dst, 1, 1, dst.numel(), 0, dst.numel(), 0, dst.numel())
+        if timed:
+            e1.record()
+            self.comm_timing.append((e0, e1, len(self._pending)))
         self._pending = []
+
+    def comm_summary(self):
+        """after a device sync: {"ranks", "backend", "buckets_per_step", "exposed_ms_per_step"} from the events collected while
+        `comm_timing` was a list (bench.py switches it on for the timed steps)"""
+        ev = self.comm_timing or []
+        active = dist.is_initialized() and (self.world > 1 or bool(os.environ.get("KALLE_FORCE_COMM")))
+        out = {"ranks": self.world, "backend": dist.get_backend(self.pg) if dist.is_initialized() else None,
+               "allreduce_active": bool(active), "comm_dtype": str(self.comm_dtype).replace("torch.", ""),
+               "buckets_per_step": ev[0][2] if ev else 0,
+               "exposed_ms_per_step": (sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)) if ev else 0.0}
+        return out
 
     # -- one micro-batch ------------------------------------------------------------------------------------
     def backward(self, loss):
@@ -302,16 +323,29 @@ class DataParallelTrainer:
         self.backward(loss)
         return loss.detach()
 
-    # -- checkpointing (reference: weights only, train_offline.py:261-263; here optimizer state too) -----------
+    # -- checkpointing (reference: weights only, train_offline.py:261-263; here the optimizer, schedule position, gradient-
+    #    accumulation phase and the EMA too, so that a resumed run continues bit for bit) -------------------------------------
     def state_dict(self):
-        return {"model": self.model.state_dict(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "step": self.step_count}
+        sd = {"model": self.model.state_dict(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+              "step": self.step_count, "micro": self.micro}
+        if getattr(self, "ema", None) is not None:
+            sc = self.ema_schedule
+            sd["ema"] = self.ema
+            sd["ema_schedule"] = {"step": sc.step, "initted": sc.initted}
+        return sd
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd["model"], strict=False)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = sd["step"]
+        self.micro = sd.get("micro", 0)
+        if "ema" in sd:
+            if getattr(self, "ema", None) is None:
+                self.enable_ema()
+            self.ema.copy_(sd["ema"])
+            self.ema_schedule.step = sd["ema_schedule"]["step"]
+            self.ema_schedule.initted = sd["ema_schedule"]["initted"]
         self.resync_bf16()
 
     def resync_bf16(self):

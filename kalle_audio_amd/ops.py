@@ -475,3 +475,45 @@ def llama_decode_step(plan, x, t0, cache_rows, rope, eps):
                                       plan["Hkv"], plan["inner"], eps, t0, cache_rows, _p(rope[0]), _p(rope[1]),
                                       _p(plan["ws"]), _stream()), "kalle_llama_decode_step")
     return out
+
+
+def gauss_kl2_fwd(pred, label_mean, label_std, mask_a, mask_b, std_mult=1.25):
+    """two-Gaussian KL (model.py:84-100); label_std None -> label_mean is the raw mean | scale label [rows, 2 dim]"""
+    lib = _lib.load()
+    rows, d2 = pred.shape
+    sums = torch.zeros(4, device=pred.device, dtype=torch.float32)
+    check(lib.kalle_gauss_kl2_fwd(_p(pred), _p(label_mean), _p(label_std), 0 if label_std is not None else 1, float(std_mult),
+                                  _p(mask_a), _p(mask_b), _p(sums), rows, d2 // 2, _stream()), "kalle_gauss_kl2_fwd")
+    return sums
+
+
+def gauss_kl2_bwd(pred, label_mean, label_std, mask_a, mask_b, sums, grad_a, grad_b, std_mult=1.25):
+    lib = _lib.load()
+    rows, d2 = pred.shape
+    dpred = torch.empty_like(pred)
+    check(lib.kalle_gauss_kl2_bwd(_p(pred), _p(label_mean), _p(label_std), 0 if label_std is not None else 1, float(std_mult),
+                                  _p(mask_a), _p(mask_b), _p(sums), _p(grad_a), _p(grad_b), _p(dpred), rows, d2 // 2,
+                                  _stream()), "kalle_gauss_kl2_bwd")
+    return dpred
+
+
+def segment_copy(src, dst, src_off, dst_off, lens, nbatch, rows, *, src_strides, dst_strides):
+    """kalle_segment_copy: per segment s, dst[s, b, c, dst_off[s] + j] = src[s, b, c, src_off[s] + j], j < lens[s]; strides =
+    (segment, batch, row) in elements; every segment in one launch (groups of KALLE_MAX_SEGMENTS)"""
+    lib = _lib.load()
+    assert src.dtype == dst.dtype
+    MAXS = 64
+    esz = src.element_size()
+    for g in range(0, len(lens), MAXS):
+        n = min(MAXS, len(lens) - g)
+        so = (ctypes.c_int64 * n)(*[int(v) for v in src_off[g:g + n]])
+        do = (ctypes.c_int64 * n)(*[int(v) for v in dst_off[g:g + n]])
+        ln = (ctypes.c_int * n)(*[int(v) for v in lens[g:g + n]])
+        sp = ctypes.c_void_p(src.data_ptr() + g * src_strides[0] * esz)
+        dp = ctypes.c_void_p(dst.data_ptr() + g * dst_strides[0] * esz)
+        if not src.is_cuda or not dst.is_cuda:
+            raise RuntimeError("kalle_audio_amd ops run on the GPU only (HIP kernels); got a CPU tensor")
+        check(lib.kalle_segment_copy(sp, dp, _dt(src), n, so, do, ln, nbatch, rows, src_strides[0], src_strides[1],
+                                     src_strides[2], dst_strides[0], dst_strides[1], dst_strides[2], _stream()),
+              "kalle_segment_copy")
+    return dst

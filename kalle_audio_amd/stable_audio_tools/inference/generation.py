@@ -1,32 +1,53 @@
-"""generate_diffusion_cond (stable_audio_tools/inference/generation.py:90-250), reduced to the DiT + v/rectified-flow
-samplers this build carries: seed -> noise (138-142 convention: torch.manual_seed(seed); randn on the device) ->
-sampler with batched CFG -> pretransform.decode."""
+"""generate_diffusion_cond (stable_audio_tools/inference/generation.py:90-250) for the DiT + the in-tree samplers this
+build carries: seed -> noise (138-142: torch.manual_seed(seed); randn on `device`) -> conditioning inputs (150-162) ->
+sampler with batched CFG (221-234) -> pretransform.decode (244-247).
+
+Objectives: "rectified_flow" runs sample_rf -> sample_discrete_euler exactly as the reference (sampling.py:200-232);
+"v" is routed by the reference to third-party k-diffusion (`sample_k`, absent here) - this build runs the in-tree v-DDIM
+sampler instead (sampling.py:47-86, the call the reference keeps commented out at generation.py:236).  Inpainting /
+variations (init_audio, mask_args) are not carried over."""
 import numpy as np
 import torch
 
 from .sampling import sample, sample_discrete_euler
 
 
-def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning=None, conditioning_tensors=None,
-                            negative_conditioning_tensors=None, batch_size: int = 1, sample_size: int = 2097152,
-                            seed: int = -1, device: str = "cuda", return_latents=False, eta=0.0, **sampler_kwargs):
-    audio_sample_size = sample_size
+def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: dict = None, conditioning_tensors=None,
+                            negative_conditioning: dict = None, negative_conditioning_tensors=None, batch_size: int = 1,
+                            sample_size: int = 2097152, sample_rate: int = 48000, seed: int = -1, device: str = "cuda",
+                            init_audio=None, init_noise_level: float = 1.0, mask_args: dict = None, return_latents=False,
+                            eta=0.0, **sampler_kwargs):
+    if init_audio is not None or mask_args is not None:
+        raise NotImplementedError("generate_diffusion_cond(init_audio / mask_args): inpainting and variations are not built")
     if model.pretransform is not None:
         sample_size = sample_size // model.pretransform.downsampling_ratio
     seed = seed if seed != -1 else np.random.randint(0, 2 ** 32 - 1, dtype=np.uint32)
     torch.manual_seed(int(seed))
-    noise = torch.randn([batch_size, model.io_channels, sample_size], device=device)
+    # the initial noise immediately after the seed (generation.py:141-142).  `device` is where the reference draws it; the
+    # kernels run on the model's device, so a CPU draw (bit-identical to the reference's CPU draw) is moved over.
+    model_device = next(model.model.parameters()).device
+    noise = torch.randn([batch_size, model.io_channels, sample_size], device=device).to(model_device)
+    assert conditioning is not None or conditioning_tensors is not None, \
+        "Must provide either conditioning or conditioning_tensors"
     if conditioning_tensors is None:
-        conditioning_tensors = model.conditioner(conditioning, device)
+        conditioning_tensors = model.conditioner(conditioning, model_device)
     cond_inputs = model.get_conditioning_inputs(conditioning_tensors)
-    neg = model.get_conditioning_inputs(negative_conditioning_tensors, negative=True) \
-        if negative_conditioning_tensors is not None else {}
+    if negative_conditioning is not None or negative_conditioning_tensors is not None:
+        if negative_conditioning_tensors is None:
+            negative_conditioning_tensors = model.conditioner(negative_conditioning, model_device)
+        neg = model.get_conditioning_inputs(negative_conditioning_tensors, negative=True)
+    else:
+        neg = {}
+    for k in ("sigma_min", "sampler_type", "sigma_max", "rho"):      # k-diffusion knobs of the reference's call sites
+        sampler_kwargs.pop(k, None)
     if model.diffusion_objective == "v":
         sampled = sample(model.model, noise, steps, eta, **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True,
-                         **sampler_kwargs)
-    else:
+                         rescale_cfg=True, **sampler_kwargs)
+    elif model.diffusion_objective == "rectified_flow":
         sampled = sample_discrete_euler(model.model, noise, steps, **cond_inputs, **neg, cfg_scale=cfg_scale,
-                                        batch_cfg=True, **sampler_kwargs)
+                                        batch_cfg=True, rescale_cfg=True, **sampler_kwargs)
+    else:
+        raise ValueError(f"unknown diffusion objective {model.diffusion_objective!r}")
     if model.pretransform is not None and not return_latents:
-        sampled = model.pretransform.decode(sampled)
+        sampled = model.pretransform.decode(sampled.float())
     return sampled

@@ -312,81 +312,81 @@ class AudioAutoencoder(nn.Module):
             decoded = torch.tanh(decoded)
         return decoded
 
+    # ---- chunked encode / decode (autoencoders.py:429-560) as a batched pipeline ------------------------------------------
+    # The reference walks the chunks one by one (one encoder / decoder pass each, paste on the way).  Here the chunk layout
+    # is planned once on the host, all chunks of all batch items ride on the batch axis of ONE pass (kalle_segment_copy
+    # gathers them), and a second kalle_segment_copy pastes the trimmed centres - the same samples land in the same places.
+    chunk_batch = 64          # most (chunk, item) rows per encoder / decoder pass
+
     @staticmethod
-    def _chunks(x, chunk_size, hop_size):
-        total = x.shape[2]
-        starts = list(range(0, total - chunk_size + 1, hop_size))
-        chunks = [x[:, :, i:i + chunk_size] for i in starts]
-        if not starts or starts[-1] + chunk_size != total:
-            chunks.append(x[:, :, -chunk_size:])
-        return chunks
+    def _chunk_plan(total_in, chunk_in, hop_in, to_out, chunk_out, total_out, trim):
+        """Where each chunk is read and which part of its result is kept.
+        Chunks start every `hop_in` input positions; when they do not end exactly at the signal's end, one more chunk is
+        anchored there (autoencoders.py:462-466, 524-528).  A chunk's result covers `chunk_out` output positions from
+        to_out(start); `trim` positions are dropped on every edge that touches a neighbour (480-490, 545-555); the anchored
+        last chunk ends at total_out.  The reference pastes in order, so where two kept regions overlap the later chunk wins:
+        the earlier region is cut back to the later one's start.  Returns [(src_start, keep_from, dst_start, length)]."""
+        if chunk_in > total_in:
+            raise ValueError(f"chunked processing needs at least one full chunk: {total_in} < chunk size {chunk_in} "
+                             "(the reference fails here too: autoencoders.py:462-466); use chunked=False")
+        starts = list(range(0, total_in - chunk_in + 1, hop_in))
+        anchored = starts[-1] + chunk_in != total_in
+        if anchored:
+            starts.append(total_in - chunk_in)
+        n = len(starts)
+        spans = []
+        for i, s0 in enumerate(starts):
+            lo = total_out - chunk_out if (i == n - 1) else to_out(s0)
+            hi = lo + chunk_out
+            keep = 0
+            if i > 0:
+                lo, keep = lo + trim, trim
+            if i < n - 1:
+                hi -= trim
+            spans.append([s0, keep, lo, hi])
+        for i in range(n - 2, -1, -1):
+            spans[i][3] = min(spans[i][3], spans[i + 1][2])
+        return [(s0, keep, lo, max(hi - lo, 0)) for s0, keep, lo, hi in spans]
+
+    def _run_chunked(self, fn, x, plan, chunk_in, total_out):
+        from .... import ops
+        B, C, _ = x.shape
+        x = x.contiguous()
+        y_final = None
+        per_pass = max(1, self.chunk_batch // B)
+        for g0 in range(0, len(plan), per_pass):
+            grp = plan[g0:g0 + per_pass]
+            n = len(grp)
+            stacked = torch.empty((n * B, C, chunk_in), device=x.device, dtype=x.dtype)
+            ops.segment_copy(x, stacked, [p[0] for p in grp], [0] * n, [chunk_in] * n, B, C,
+                             src_strides=(0, x.stride(0), x.stride(1)), dst_strides=(B * C * chunk_in, C * chunk_in, chunk_in))
+            y = fn(stacked).contiguous()                                   # ONE encoder / decoder pass for n chunks
+            Cy, Ly = y.shape[1], y.shape[2]
+            if y_final is None:
+                y_final = torch.zeros((B, Cy, total_out), device=x.device, dtype=y.dtype)
+            ops.segment_copy(y, y_final, [p[1] for p in grp], [p[2] for p in grp], [p[3] for p in grp], B, Cy,
+                             src_strides=(B * Cy * Ly, Cy * Ly, Ly), dst_strides=(0, y_final.stride(0), y_final.stride(1)))
+        return y_final
 
     def encode_audio(self, audio, chunked=False, overlap=32, chunk_size=128, **kwargs):
-        """autoencoders.py:429-497: overlap-and-paste over chunks measured in latents."""
+        """autoencoders.py:429-497; chunk_size / overlap in latents"""
         if not chunked:
             return self.encode(audio, **kwargs)
-        spl = self.downsampling_ratio
-        total_size, batch_size = audio.shape[2], audio.shape[0]
-        chunk_size *= spl
-        overlap *= spl
-        hop_size = chunk_size - overlap
-        chunks = self._chunks(audio, chunk_size, hop_size)
-        num_chunks = len(chunks)
-        y_size = total_size // spl
-        y_final = None
-        for i in range(num_chunks):
-            y_chunk = self.encode(chunks[i])
-            if y_final is None:
-                y_final = torch.zeros((batch_size, y_chunk.shape[1], y_size), device=audio.device, dtype=y_chunk.dtype)
-            if i == num_chunks - 1:
-                t_end = y_size
-                t_start = t_end - y_chunk.shape[2]
-            else:
-                t_start = i * hop_size // spl
-                t_end = t_start + chunk_size // spl
-            ol = overlap // spl // 2
-            chunk_start, chunk_end = 0, y_chunk.shape[2]
-            if i > 0:
-                t_start += ol
-                chunk_start += ol
-            if i < num_chunks - 1:
-                t_end -= ol
-                chunk_end -= ol
-            y_final[:, :, t_start:t_end] = y_chunk[:, :, chunk_start:chunk_end]
-        return y_final
+        r = self.downsampling_ratio
+        chunk_in, hop_in = chunk_size * r, (chunk_size - overlap) * r
+        total_out = audio.shape[2] // r
+        plan = self._chunk_plan(audio.shape[2], chunk_in, hop_in, lambda s0: s0 // r, chunk_size, total_out, overlap // 2)
+        return self._run_chunked(lambda c: self.encode(c, **kwargs), audio, plan, chunk_in, total_out)
 
     def decode_audio(self, latents, chunked=False, overlap=32, chunk_size=128, **kwargs):
         """autoencoders.py:499-560"""
         if not chunked:
             return self.decode(latents, **kwargs)
-        hop_size = chunk_size - overlap
-        total_size, batch_size = latents.shape[2], latents.shape[0]
-        chunks = self._chunks(latents, chunk_size, hop_size)
-        num_chunks = len(chunks)
-        spl = self.downsampling_ratio
-        y_size = total_size * spl
-        y_final = None
-        for i in range(num_chunks):
-            y_chunk = self.decode(chunks[i].contiguous())
-            if y_final is None:
-                y_final = torch.zeros((batch_size, self.out_channels, y_size), device=latents.device,
-                                      dtype=y_chunk.dtype)
-            if i == num_chunks - 1:
-                t_end = y_size
-                t_start = t_end - y_chunk.shape[2]
-            else:
-                t_start = i * hop_size * spl
-                t_end = t_start + chunk_size * spl
-            ol = (overlap // 2) * spl
-            chunk_start, chunk_end = 0, y_chunk.shape[2]
-            if i > 0:
-                t_start += ol
-                chunk_start += ol
-            if i < num_chunks - 1:
-                t_end -= ol
-                chunk_end -= ol
-            y_final[:, :, t_start:t_end] = y_chunk[:, :, chunk_start:chunk_end]
-        return y_final
+        r = self.downsampling_ratio
+        total_out = latents.shape[2] * r
+        plan = self._chunk_plan(latents.shape[2], chunk_size, chunk_size - overlap, lambda s0: s0 * r, chunk_size * r,
+                                total_out, (overlap // 2) * r)
+        return self._run_chunked(lambda c: self.decode(c, **kwargs), latents, plan, chunk_size, total_out)
 
 
 def create_encoder_from_config(encoder_config: Dict[str, Any]):

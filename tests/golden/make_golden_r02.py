@@ -329,7 +329,30 @@ def training_step():
     save("training_step", **out)
 
 
-ALL = dict(wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
+def chunked_vae():
+    """AudioAutoencoder.decode_audio(chunked=True) of the reference (autoencoders.py:499-560): an anchored last chunk, and an
+    odd overlap (kept regions of neighbours then overlap by one latent and the later chunk wins).  The reference's chunked
+    ENCODE cannot run on this model: its paste buffer has latent_dim channels (autoencoders.py:472) while the pass-through VAE
+    bottleneck of this reference returns 2 * latent_dim (bottleneck.py:89-100) - the assignment at :496 raises."""
+    from stable_audio_tools.models.factory import create_model_from_config
+    ae = load_seeded(create_model_from_config(gu.oobleck_cfg(True)), 23)
+    z = T(gu.make_input("zc", (2, 4, 125), 65))
+    out = {}
+    with torch.no_grad():
+        out["dec_48_16"] = ae.decode_audio(z, chunked=True, chunk_size=48, overlap=16)
+        out["dec_48_15"] = ae.decode_audio(z, chunked=True, chunk_size=48, overlap=15)
+        out["dec_full"] = ae.decode_audio(z, chunked=False)
+        wav = T(gu.make_input("wavc", (2, 2, 5000), 65, 0.5))
+        try:
+            ae.encode_audio(wav, chunked=True, chunk_size=48, overlap=16)
+            out["enc_chunked_runs"] = np.array(1)
+        except RuntimeError:
+            out["enc_chunked_runs"] = np.array(0)
+        out["enc_full"] = ae.encode_audio(wav, chunked=False)
+    save("chunked_vae", **out)
+
+
+ALL = dict(chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
            training_step=training_step, model_llasa=model_llasa)
 
 

@@ -462,3 +462,69 @@ def test_training_step_wrapper(tag, objective, pre, seed):
     loss.backward()
     assert abs(loss.item() - f[f"{tag}/loss"].item()) < 2e-5 * abs(loss.item()), (loss.item(), f[f"{tag}/loss"].item())
     check_digests_n(f, sd_dit, 16, prefix=f"{tag}/", tol=1e-4, strip="model.")
+
+
+def _paste_in_order(total_lat, chunk, overlap, r):
+    """the reference's loop semantics (autoencoders.py:529-559) as a map output position -> (chunk, position in the chunk)"""
+    hop = chunk - overlap
+    starts = list(range(0, total_lat - chunk + 1, hop))
+    if starts[-1] + chunk != total_lat:
+        starts.append(total_lat - chunk)
+    y = -np.ones((total_lat * r, 2), dtype=np.int64)
+    n = len(starts)
+    for i in range(n):
+        if i == n - 1:
+            te = total_lat * r
+            ts = te - chunk * r
+        else:
+            ts = i * hop * r
+            te = ts + chunk * r
+        ol = (overlap // 2) * r
+        cs, ce = 0, chunk * r
+        if i > 0:
+            ts, cs = ts + ol, cs + ol
+        if i < n - 1:
+            te, ce = te - ol, ce - ol
+        y[ts:te, 0] = i
+        y[ts:te, 1] = np.arange(cs, ce)
+    return y, starts
+
+
+@pytest.mark.parametrize("total,chunk,ov,r", [(125, 48, 16, 40), (125, 48, 15, 40), (96, 48, 16, 40), (750, 128, 32, 32),
+                                              (130, 128, 32, 4), (128, 128, 32, 4), (1000, 128, 0, 8)])
+def test_chunk_plan_equals_paste_in_order(total, chunk, ov, r):
+    """host logic of the batched chunk pipeline (no GPU): disjoint destinations, and the same (chunk, sample) at every output
+    position as pasting the chunks one after another"""
+    from kalle_audio_amd.stable_audio_tools.models.autoencoders import AudioAutoencoder
+    plan = AudioAutoencoder._chunk_plan(total, chunk, chunk - ov, lambda s0: s0 * r, chunk * r, total * r, (ov // 2) * r)
+    want, starts = _paste_in_order(total, chunk, ov, r)
+    assert [p[0] for p in plan] == starts
+    got = -np.ones_like(want)
+    cover = np.zeros(total * r, dtype=int)
+    for i, (s0, keep, lo, ln) in enumerate(plan):
+        got[lo:lo + ln, 0] = i
+        got[lo:lo + ln, 1] = np.arange(keep, keep + ln)
+        cover[lo:lo + ln] += 1
+    assert (cover == 1).all()
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        AudioAutoencoder._chunk_plan(chunk - 1, chunk, chunk - ov, lambda s0: s0 * r, chunk * r, (chunk - 1) * r, 0)
+
+
+def test_chunked_decode_fixture_is_consistent_with_oracle():
+    """oracle decode + the paste-in-order map reproduces the reference's chunked decode (and its unchunked one)"""
+    f = fx("chunked_vae")
+    vshapes = (ko.oobleck_encoder_shapes(2, 8, 8, [1, 2, 4], [2, 4, 5], True, "encoder.") +
+               ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], True, "decoder."))
+    sd = state(vshapes, 23, False)
+    z = T(gu.make_input("zc", (2, 4, 125), 65))
+    with torch.no_grad():
+        close(ko.pretransform_decode(sd, z, [2, 4, 5], True), f["dec_full"], 1e-5)
+        for ov, key in ((16, "dec_48_16"), (15, "dec_48_15")):
+            want, starts = _paste_in_order(125, 48, ov, 40)
+            chunks = [ko.pretransform_decode(sd, z[:, :, s0:s0 + 48], [2, 4, 5], True) for s0 in starts]
+            out = torch.zeros(2, 2, 5000)
+            for pos in range(5000):
+                out[:, :, pos] = chunks[want[pos, 0]][:, :, want[pos, 1]]
+            close(out, f[key], 1e-5)
+    assert int(f["enc_chunked_runs"]) == 0       # the reference's chunked encode raises on its own pass-through bottleneck
