@@ -117,7 +117,14 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get("KALLE_TRACE")      # debugging aid: name every C-ABI call on stderr and wait for it to finish
+
+
 def check(code, what):
+    if _TRACE:
+        import sys
+        print("[kalle] " + what, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if code != 0:
         detail = ""
         if code == -2 and _lib is not None:

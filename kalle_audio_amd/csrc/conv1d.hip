@@ -356,7 +356,12 @@ __device__ __forceinline__ void conv_core(const ConvParams& p, const ConvPass& g
             }
         }
     };
-    const cfloat_p wbase = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.w)) + co_w;
+    // A wave whose channel group lies wholly beyond the packed row (Cout = 16 under a 32-channel workgroup: waves 2, 3) still
+    // runs the loop for the barriers and the staging; its weight reads are redirected to column 0 - read at co_w they would
+    // run up to COW floats past the END of the array on the last (ci, tap) row (a fault when the array ends a mapped segment).
+    // (A group that is partly valid needs CoutP % COW == 0: pick_tile only offers COW = 16 then.)
+    const int co_ld = co_w + COW <= p.CoutP ? co_w : 0;
+    const cfloat_p wbase = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(p.w)) + co_ld;
     const cfloat_p wlast = wbase + ((int64_t)p.Cin * p.K - 1) * p.CoutP;
     const int nwrap = (g.ph0 + g.ntaps - 1) / g.S;   // phase wraps among the ntaps-1 advances of one channel
     const int xwrap = SPAN - ((g.ntaps - 1 - nwrap) * g.xtap + nwrap * g.xtap_wrap);
@@ -982,7 +987,7 @@ TileChoice pick_tile(int64_t npos, int Cout, int B, int halo, int span, int lpt_
     for (int i = 0; i < 4; ++i) {
         const int lt = 64 * lpts[i], cot = 4 * cows[i];
         if (lt + halo > span || (lpt_only && lpts[i] != lpt_only)) continue;
-        if (cows[i] == 16 && Cout < 64) continue;
+        if (cows[i] == 16 && (Cout < 64 || ((Cout + 7) & ~7) % 16)) continue;   // (16-wide weight reads need CoutP % 16 == 0)
         const int64_t nwg = ((npos + lt - 1) / lt) * ((Cout + cot - 1) / cot) * B * wg_mult;
         // rounds: 2 (COW 16) / 3 (COW 8) workgroups fit a CU; a lone workgroup per CU still costs ~0.6 of a full round
         const int64_t slots = 256 * (cows[i] == 16 ? 2 : 3);
@@ -1049,7 +1054,7 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
                 }
             }
         } else if (Cout > 4) {                           // stride 2 / 4 / 8: de-interleaved staging, 1024/stride positions
-            const bool wide = Cout >= 64;
+            const bool wide = Cout >= 64 && p.CoutP % 16 == 0;
             if (stride == 2) KALLE_CONV_V2(8, 8, 4, 8, 1088);
             if (stride == 4) { if (wide) KALLE_CONV_V2(16, 4, 4, 8, 1088); else KALLE_CONV_V2(8, 4, 4, 8, 1088); }
             if (stride == 8 && (int64_t)Lout * B <= 1024) KALLE_CONV_V2(8, 2, 4, 8, 1088);   // longer: fallback is faster

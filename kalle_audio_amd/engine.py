@@ -331,7 +331,9 @@ class DataParallelTrainer:
         if getattr(self, "ema", None) is not None:
             sc = self.ema_schedule
             sd["ema"] = self.ema
-            sd["ema_schedule"] = {"step": sc.step, "initted": sc.initted}
+            sd["ema_schedule"] = {"step": sc.step, "initted": sc.initted, "beta": sc.beta, "power": sc.power,
+                                  "update_every": sc.update_every, "update_after_step": sc.update_after_step,
+                                  "inv_gamma": sc.inv_gamma, "min_value": sc.min_value}
         return sd
 
     def load_state_dict(self, sd):
@@ -341,11 +343,11 @@ class DataParallelTrainer:
         self.step_count = sd["step"]
         self.micro = sd.get("micro", 0)
         if "ema" in sd:
-            if getattr(self, "ema", None) is None:
-                self.enable_ema()
+            es = dict(sd["ema_schedule"])
+            step, initted = es.pop("step"), es.pop("initted")
+            self.enable_ema(**es)                      # the decay schedule travels with the checkpoint
             self.ema.copy_(sd["ema"])
-            self.ema_schedule.step = sd["ema_schedule"]["step"]
-            self.ema_schedule.initted = sd["ema_schedule"]["initted"]
+            self.ema_schedule.step, self.ema_schedule.initted = step, initted
         self.resync_bf16()
 
     def resync_bf16(self):

@@ -35,36 +35,60 @@ def _mask8(m):
     return m.to(torch.uint8).contiguous()
 
 
+def _pad8(t, rows=False):
+    """zero-pad the last dim (and optionally the first) of a 2-D tensor to a multiple of 8 - the GEMM's granule.  Only odd
+    channel counts get here (io_channels 4 in tests; the reference's configs use 64 / 512 / 1024); zeros add nothing to a dot
+    product, padded output columns are sliced off."""
+    pc = (-t.shape[-1]) % 8
+    pr = (-t.shape[0]) % 8 if rows else 0
+    return torch.nn.functional.pad(t, (0, pc, 0, pr)) if (pc or pr) else t
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T (+ b) (+ residual); x: [..., K] (bf16 or fp32), W: [N, K] fp32 parameter."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, out_dtype):
         shp = x.shape
-        xb = _to_bf16(x.contiguous()).view(-1, shp[-1])
+        N, K = weight.shape
+        xb = _to_bf16(x.contiguous()).view(-1, K)
         wb = D.bf16_of(weight)
-        res = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
-        y = ops.gemm(xb, wb, bias=D.f32_of(bias) if bias is not None else None, residual=res, out_dtype=out_dtype)
+        res = residual.contiguous().view(-1, N) if residual is not None else None
+        b32 = D.f32_of(bias) if bias is not None else None
+        ctx.padded = bool(K % 8 or N % 8)
+        if ctx.padded:
+            xb, wb = _pad8(xb), _pad8(wb, rows=True)
+            res = _pad8(res) if res is not None else None
+            b32 = torch.nn.functional.pad(b32, (0, (-N) % 8)) if b32 is not None else None
+        y = ops.gemm(xb, wb, bias=b32, residual=res, out_dtype=out_dtype)
+        if ctx.padded:
+            y = y[:, :N].contiguous()
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.x_dtype = x.dtype
         ctx.shp = shp
-        return y.view(*shp[:-1], weight.shape[0])
+        return y.view(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         xb, weight = ctx.saved_tensors
+        N, K = weight.shape
         wb = D.bf16_of(weight)
-        dyc = dy.contiguous().view(-1, weight.shape[0])
+        dyc = dy.contiguous().view(-1, N)
         gb = _to_bf16(dyc)
+        if ctx.padded:
+            gb, wb = _pad8(gb), _pad8(wb, rows=True)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _like(D.dgrad(gb, wb), ctx.x_dtype).view(ctx.shp)
+            dx = D.dgrad(gb, wb)
+            dx = _like(dx[:, :K].contiguous() if ctx.padded else dx, ctx.x_dtype).view(ctx.shp)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm(gb, xb, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+            dw = dw[:N, :K].contiguous() if ctx.padded else dw
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(gb)
+            db = db[:N].contiguous() if ctx.padded else db
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         return dx, dw, db, dres, None

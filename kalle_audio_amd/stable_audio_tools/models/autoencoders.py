@@ -349,7 +349,7 @@ class AudioAutoencoder(nn.Module):
         return [(s0, keep, lo, max(hi - lo, 0)) for s0, keep, lo, hi in spans]
 
     def _run_chunked(self, fn, x, plan, chunk_in, total_out):
-        from .... import ops
+        from ... import ops
         B, C, _ = x.shape
         x = x.contiguous()
         y_final = None

@@ -227,9 +227,11 @@ class ContinuousTransformer(nn.Module):
         else:
             x = KF.SpliceFn.apply(None, x)
         rotary = self.rotary_pos_emb.forward_from_seq_len(x.shape[1]) if self.rotary_pos_emb is not None else None
-        # an all-true mask is the common case (dit.py:189): skip the masked kernels' extra work
-        if mask is not None and bool(mask.all()):
-            mask = None
+        # transformer.py:800-802 calls every layer with rotary_pos_emb, global_cond and **kwargs only: the mask assembled above
+        # is never handed to the layers, so padding masks do not reach the self-attention of a ContinuousTransformer (the
+        # reference's behaviour, pinned by tests/golden/training_step.npz).  TransformerBlock / Attention called directly
+        # do honour `mask`.
+        mask = None
         ctx = kwargs.get("context")
         if ctx is not None and not ctx.requires_grad and ctx.dtype == torch.float32:
             # frozen conditioning (T5 / number embedders): one bf16 cast for all layers instead of one per layer

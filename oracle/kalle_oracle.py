@@ -164,8 +164,11 @@ def continuous_transformer(sd, x, depth, mask=None, prepend_embeds=None, prepend
             prepend_mask = prepend_mask if prepend_mask is not None else torch.ones(B, P, dtype=torch.bool)
             mask = torch.cat([prepend_mask, mask], -1)
     rot = rotary_freqs(x.shape[1], max(dim_heads // 2, 32))
+    # transformer.py:800-802: the layers are called with rotary_pos_emb, global_cond and **kwargs (context, context_mask) -
+    # the assembled `mask` is NOT handed on, so a padding mask never reaches the self-attention of a ContinuousTransformer
+    # (pinned by tests/golden/training_step.npz, whose steps run with mask_padding=True)
     for i in range(depth):
-        x = transformer_block(_sub(sd, f"layers.{i}."), x, context=context, global_cond=global_cond, mask=mask,
+        x = transformer_block(_sub(sd, f"layers.{i}."), x, context=context, global_cond=global_cond, mask=None,
                               context_mask=context_mask, rotary=rot, dim_heads=dim_heads)
     if "project_out.weight" in sd:
         x = linear(x, sd["project_out.weight"])
