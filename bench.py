@@ -192,12 +192,21 @@ def main():
         }
         if timer:
             agg = {}
-            for variant, fl, e0, e1, ab in timer:
+            shapes = {}
+            for variant, fl, e0, e1, ab, shp in timer:
+                sa = shapes.setdefault((variant, shp), [0.0, 0.0, 0])
+                sa[0] += fl
+                sa[1] += e0.elapsed_time(e1) * 1e-3
+                sa[2] += 1
                 a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
                 a[0] += fl
                 a[1] += e0.elapsed_time(e1) * 1e-3
                 a[2] += 1
                 a[3] += ab
+            if os.environ.get("KALLE_BENCH_SHAPES"):        # per-shape table on stderr (not part of the JSON line)
+                for (variant, shp), (fl, sec, n) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    print(f"[shape] {variant:34s} M,N,K={shp}  {n // args.steps:3d}/step  {sec / n * 1e6:8.1f} us  "
+                          f"{fl / sec / 1e12:7.0f} TFLOP/s  {100 * sec / dt:5.2f} % of step", file=sys.stderr)
             dom = max(agg.items(), key=lambda kv: kv[1][1])
             name, (fl, sec, n, ab) = dom
             ach = fl / sec / 1e12

@@ -72,7 +72,7 @@ int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int
                     const kalle_gemm_epilogue* ep, void* stream);
 
 /* which kernel the calling thread's most recent kalle_gemm_bf16 used: low byte 1 = gemm_bf16_kernel (128x128,
- * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 64 == 0), 3 = gemm3_kernel (256x256, 2 stages); bits 8.. =
+ * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 8 == 0), 3 = gemm3_kernel (256x256, 2 stages); bits 8.. =
  * split-K factor */
 int kalle_gemm_last_plan(void);
 
@@ -170,6 +170,25 @@ int kalle_transpose_2d(const void* in, int in_dtype, int64_t in_batch_stride, in
 int kalle_copy_rows(const void* in, int in_dtype, int64_t in_batch_stride, int64_t in_ld, void* out,
                     int out_dtype, int64_t out_batch_stride, int64_t out_ld, int nbatch, int rows, int cols,
                     int accumulate, void* stream);
+
+/* All weight gradients of a transformer block in ONE launch: dw_i [N_i][K_i] += dy_i^T x_i over `tokens` rows
+ * (the autograd backward of the block's nn.Linear layers - transformer.py:216,252,411,414,419,541 - which the reference
+ * leaves to torch, one GEMM each).  dy bf16 [tokens][N] (ld lddy), x bf16 [tokens][K] (ld ldx), dw fp32 [N][K] (ld lddw),
+ * ACCUMULATED into (the trainer's gradient sink; zero it for a plain gradient).  N, K, lddy, ldx % 8 == 0, 16-byte aligned
+ * pointers; tokens % 8 != 0 returns KALLE_ERR_UNSUPPORTED (launch the gradients one by one with kalle_gemm_bf16 then).
+ * Most 256 x 256 output tiles run over all tokens (read-add-store), a tail is cut into token slices (atomic adds) so that
+ * the last round of workgroups is full. */
+#define KALLE_MAX_GROUP 8
+typedef struct kalle_wgrad_problem {
+    const void* dy;
+    int64_t lddy;
+    const void* x;
+    int64_t ldx;
+    float* dw;
+    int64_t lddw;
+    int32_t N, K, tokens;
+} kalle_wgrad_problem;
+int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, void* stream);
 
 /* Chunked VAE encode / decode (AudioAutoencoder.encode_audio / decode_audio, autoencoders.py:429-560) as a batched pipeline:
  * every chunk rides on the batch axis of ONE encoder / decoder pass; this call is the gather in front of it and the paste

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "kalle_hip.h")
-LIB_PATH = os.path.join(HERE, "libkalle_hip.so")
+LIB_PATH = os.environ.get("KALLE_LIB_PATH") or os.path.join(HERE, "libkalle_hip.so")   # (override: A/B two builds on one box)
 
 KALLE_BF16 = 0
 KALLE_F32 = 1
@@ -60,6 +60,13 @@ class LlamaLayer(ctypes.Structure):
     _fields_ = [("input_norm", ctypes.c_void_p), ("wqkv", ctypes.c_void_p), ("wo", ctypes.c_void_p),
                 ("post_norm", ctypes.c_void_p), ("wug", ctypes.c_void_p), ("wdown", ctypes.c_void_p),
                 ("kv_cache", ctypes.c_void_p)]
+
+
+class WgradProblem(ctypes.Structure):
+    """Mirror of `kalle_wgrad_problem`."""
+    _fields_ = [("dy", ctypes.c_void_p), ("lddy", ctypes.c_int64), ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+                ("dw", ctypes.c_void_p), ("lddw", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("tokens", ctypes.c_int32)]
 
 
 _CTYPE = {

@@ -12,7 +12,7 @@
 //                                 position p at slot c ^ (2*(p&7))                                (ds_read_b64_tr_b16)
 // Split-K (wgrad: the output is weight-shaped, the contraction runs over all tokens) turns the grid into
 // tiles x splits with fp32 atomics into a zeroed C - this is what fills 256 CUs when the output has < 256 tiles.
-// Requirements: K % 64 == 0 (otherwise the dispatcher uses the 128x128 kernel of gemm.hip).
+// Requirements: K % 8 == 0 (a ragged last K-tile takes its missing 16-byte pieces from a block of zeros).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,6 +28,10 @@ namespace {
 
 constexpr int BK2 = 64;
 #define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 64 zero bytes: the source of every 16-byte piece of a ragged last K-tile that lies beyond K (an LDS-DMA load has no range
+// check and no per-lane predicate, but its SOURCE address is per lane)
+__device__ __attribute__((aligned(64))) const unsigned kalle_zero_block[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // ---- LDS-DMA issue for one operand region -------------------------------------------------------------------------
 // R: tile extent (rows of a k-contiguous operand / contiguous extent of a k-major one); NW waves share R/8 1-KiB pieces
@@ -73,6 +77,33 @@ struct Loader {
             __builtin_amdgcn_global_load_lds(GPTR(src[i]), LDS_PTR(void, region + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
             src[i] += kstep;
         }
+    }
+    // the ragged last K-tile (K % 64 != 0): only the first `kvalid` (a multiple of 8) of its 64 k exist; every piece that lies
+    // beyond them is fetched from the zero block instead, so both operands contribute exact zeros there
+    __device__ __forceinline__ void issue_tail(char* region, int wave, int lane, int kvalid) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int q = wave * PER_WAVE + i;
+            bool ok;
+            if constexpr (!KM) {
+                const int row = 8 * q + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                ok = 8 * c < kvalid;
+            } else {
+                constexpr int RB = 2 * R, ROWS = 1024 / RB;
+                const int pos = q * ROWS + (lane * 16) / RB;
+                const int krow = (pos & ~7) | ((pos & 7) ^ (((pos >> 3) & 1) << 2));
+                ok = krow < kvalid;
+            }
+            const bf16_t* sp = ok ? src[i] : reinterpret_cast<const bf16_t*>(kalle_zero_block);
+            __builtin_amdgcn_global_load_lds(GPTR(sp), LDS_PTR(void, region + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
+            src[i] += kstep;
+        }
+    }
+    // tile index `t` of this workgroup's K range; `tail_t` = index of the ragged tile (-1: none)
+    __device__ __forceinline__ void issue_at(char* region, int wave, int lane, int t, int tail_t, int kvalid) {
+        if (t == tail_t) issue_tail(region, wave, lane, kvalid);
+        else issue(region, wave);
     }
 };
 
@@ -120,27 +151,28 @@ struct Reader {
         }
     }
     // fragments of the 4 tiles (16 operand rows each) of k-step S, stage byte offset `so`
-    template <int S, int NTILE>
+    // NTILE tiles starting at tile T0 (16 operand rows each, from rbase)
+    template <int S, int NTILE, int T0 = 0>
     __device__ __forceinline__ void read(unsigned so, i32x4 (&f)[NTILE]) const {
         if constexpr (!KM) {
             const unsigned a = b0[S] + so;
-            f[0] = lds_b128<0>(a);
-            f[1] = lds_b128<2048>(a);
-            f[2] = lds_b128<4096>(a);
-            f[3] = lds_b128<6144>(a);
+            f[0] = lds_b128<2048 * (T0 + 0)>(a);
+            f[1] = lds_b128<2048 * (T0 + 1)>(a);
+            f[2] = lds_b128<2048 * (T0 + 2)>(a);
+            f[3] = lds_b128<2048 * (T0 + 3)>(a);
             if constexpr (NTILE == 8) {
-                f[4] = lds_b128<8192>(a);
-                f[5] = lds_b128<10240>(a);
-                f[6] = lds_b128<12288>(a);
-                f[7] = lds_b128<14336>(a);
+                f[4] = lds_b128<2048 * (T0 + 4)>(a);
+                f[5] = lds_b128<2048 * (T0 + 5)>(a);
+                f[6] = lds_b128<2048 * (T0 + 6)>(a);
+                f[7] = lds_b128<2048 * (T0 + 7)>(a);
             }
         } else {
             const unsigned a0 = b0[S] + so, a1 = b1[S] + so;
 #pragma unroll
             for (int t = 0; t < NTILE; ++t) {
-                // (cl + 2t) ^ 2u == (cl ^ 2u) ^ 2t for cl % 8 == 0 -> the tile index is an XOR on address bits 5-6
-                const i32x2 lo = lds_tr(a0 ^ (t << 5));
-                const i32x2 hi = lds_tr(a1 ^ (t << 5));
+                // (cl + 2t) ^ 2u == (cl ^ 2u) ^ 2t for cl % 8 == 0 -> the tile index is an XOR on address bits 5-7
+                const i32x2 lo = lds_tr(a0 ^ ((T0 + t) << 5));
+                const i32x2 hi = lds_tr(a1 ^ ((T0 + t) << 5));
                 f[t] = i32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         }
@@ -368,9 +400,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int nk_all = p.K / BK2;
+    const int nk_all = (p.K + BK2 - 1) / BK2;
     const int kt0 = blockIdx.y * p.ktiles_per_split;
     const int nk = min(p.ktiles_per_split, nk_all - kt0);
+    const int kvalid = p.K % BK2;                                   // ragged last K-tile (0: none)
+    const int tail_t = kvalid ? nk_all - 1 - kt0 : -1;              // its index inside this workgroup's K range
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -390,15 +424,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
 
     // prologue: up to three tiles in flight (3-stage ring), wait for tile 0 only
     constexpr int PT = Loader<A_KM, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;   // DMA pieces per tile per wave
-    la.issue(smem, wave);
-    lb.issue(smem + A_BYTES, wave);
+    la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
+    lb.issue_at(smem + A_BYTES, wave, lane, 0, tail_t, kvalid);
     if (nk > 1) {
-        la.issue(smem + STAGE, wave);
-        lb.issue(smem + STAGE + A_BYTES, wave);
+        la.issue_at(smem + STAGE, wave, lane, 1, tail_t, kvalid);
+        lb.issue_at(smem + STAGE + A_BYTES, wave, lane, 1, tail_t, kvalid);
     }
     if (nk > 2) {
-        la.issue(smem + 2 * STAGE, wave);
-        lb.issue(smem + 2 * STAGE + A_BYTES, wave);
+        la.issue_at(smem + 2 * STAGE, wave, lane, 2, tail_t, kvalid);
+        lb.issue_at(smem + 2 * STAGE + A_BYTES, wave, lane, 2, tail_t, kvalid);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
     } else if (nk > 1) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
@@ -413,6 +447,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     rb.template read<0, 4>(0, fb0);
 
     unsigned so_cur = 0, so_nxt = STAGE;   // byte offsets of the stage being computed / the next one (ring of 3)
+    int kt = 0;
 
     // one K-tile: ISSUE = start the DMA of tile kt+3, NEXT = a tile kt+1 exists, KEEP = tile kt+2's DMA stays in flight
     auto iteration = [&](auto issue_c, auto next_c, auto keep_c) {
@@ -439,8 +474,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+3 into it
-            la.issue(smem + so_cur, wave);
-            lb.issue(smem + so_cur + A_BYTES, wave);
+            la.issue_at(smem + so_cur, wave, lane, kt + 3, tail_t, kvalid);
+            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + 3, tail_t, kvalid);
         }
         // ---- k-step 1: read set 0 of the next tile while the MFMAs of set 1 issue
         if constexpr (NEXT) {
@@ -457,7 +492,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    int kt = 0;
 #pragma unroll 1
     for (; kt + 3 < nk; ++kt) iteration(T_{}, T_{}, T_{});
     if (kt + 2 < nk) { iteration(F_{}, T_{}, T_{}); ++kt; }
@@ -489,8 +523,11 @@ int launch2(const GemmParams& p, hipStream_t st) {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
                                                               __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
 
-template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
-__global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
+// one 256 x 256 output tile over K-tiles [kt0, kt0 + nk) of problem `p` (shared by the plain and the grouped kernel)
+template <bool A_KM, bool B_KM, bool C_F32, int GLU>
+__device__ __forceinline__ void gemm3_tile(const GemmParams& p, int tm, int tn, int kt0, int nk) {
+    const int kvalid = p.K % BK2;                                               // ragged last K-tile (0: none)
+    const int tail_t = kvalid ? (p.K + BK2 - 1) / BK2 - 1 - kt0 : -1;           // its index inside [0, nk)
     constexpr int WN = 4, TM = 8, NW = 8;
     constexpr int BM = 256, BN = 256;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -500,24 +537,6 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-
-    const int nk_all = p.K / BK2;
-    int tm, tn, kt0, nk;
-    if (p.mix_na >= 0) {
-        // mixed split-K: 1-D grid; blocks [0, na * sa) = tiles [0, na) x sa slices (tile fastest), then the other tiles x (sa + 1)
-        const int ntiles = p.tiles_m * p.tiles_n, na = p.mix_na, sa = p.mix_sa;
-        int bid = blockIdx.x, tile, slice, per;
-        if (bid < na * sa) { tile = bid % na; slice = bid / na; per = (nk_all + sa - 1) / sa; }
-        else { bid -= na * sa; const int nb = ntiles - na; tile = na + bid % nb; slice = bid / nb; per = (nk_all + sa) / (sa + 1); }
-        gemm_tile_coords(tile, ntiles, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        kt0 = slice * per;
-        nk = min(per, nk_all - kt0);
-        if (nk <= 0) return;                 // (uniform per workgroup)
-    } else {
-        gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        kt0 = blockIdx.y * p.ktiles_per_split;
-        nk = min(p.ktiles_per_split, nk_all - kt0);
-    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[TM][4];
@@ -536,11 +555,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
 
-    la.issue(smem, wave);
-    lb.issue(smem + A_BYTES, wave);
+    la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
+    lb.issue_at(smem + A_BYTES, wave, lane, 0, tail_t, kvalid);
     if (nk > 1) {
-        la.issue(smem + STAGE, wave);
-        lb.issue(smem + STAGE + A_BYTES, wave);
+        la.issue_at(smem + STAGE, wave, lane, 1, tail_t, kvalid);
+        lb.issue_at(smem + STAGE + A_BYTES, wave, lane, 1, tail_t, kvalid);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 + 4 DMA pieces per tile per wave
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -550,6 +569,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
 
     i32x4 fa[8], fb[4];
     unsigned so_cur = 0;
+    int kt = 0;
     const bool late = wave >= NW / 2;     // the staggered half
     if (late) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every issue arbitration by age otherwise
     // prologue of the software pipeline: k-step 0 of tile 0
@@ -580,8 +600,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+2 into it
-            la.issue(smem + so_cur, wave);
-            lb.issue(smem + so_cur + A_BYTES, wave);
+            la.issue_at(smem + so_cur, wave, lane, kt + 2, tail_t, kvalid);
+            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + 2, tail_t, kvalid);
         }
         so_cur ^= STAGE;
         if constexpr (NEXT) {
@@ -592,13 +612,96 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    int kt = 0;
 #pragma unroll 1
     for (; kt + 2 < nk; ++kt) iteration(T_{}, T_{});
     if (kt + 1 < nk) { iteration(F_{}, T_{}); ++kt; }
     iteration(F_{}, F_{});
 
     wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wave, lane, m0 + arow, GLU == 1 ? tn * 128 + wn * 32 : n0 + bcol);
+}
+
+template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
+    const int nk_all = (p.K + BK2 - 1) / BK2;
+    int tm, tn, kt0, nk;
+    if (p.mix_na >= 0) {
+        // mixed split-K: 1-D grid; blocks [0, na * sa) = tiles [0, na) x sa slices (tile fastest), then the other tiles x (sa + 1)
+        const int ntiles = p.tiles_m * p.tiles_n, na = p.mix_na, sa = p.mix_sa;
+        int bid = blockIdx.x, tile, slice, per;
+        if (bid < na * sa) { tile = bid % na; slice = bid / na; per = (nk_all + sa - 1) / sa; }
+        else { bid -= na * sa; const int nb = ntiles - na; tile = na + bid % nb; slice = bid / nb; per = (nk_all + sa) / (sa + 1); }
+        gemm_tile_coords(tile, ntiles, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        kt0 = slice * per;
+        nk = min(per, nk_all - kt0);
+        if (nk <= 0) return;                 // (uniform per workgroup)
+    } else {
+        gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        kt0 = blockIdx.y * p.ktiles_per_split;
+        nk = min(p.ktiles_per_split, nk_all - kt0);
+    }
+    gemm3_tile<A_KM, B_KM, C_F32, GLU>(p, tm, tn, kt0, nk);
+}
+
+// ================================================================================================ grouped weight gradients
+// All weight gradients of a transformer block in ONE launch (kalle_gemm_wgrad_group): dW_i[N_i, K_i] += dY_i^T X_i, every one a
+// (k-major, k-major, fp32) problem over the block's tokens.  Launched one by one they need 3 - 8 K slices each to fill 256 CUs
+// (36 - 288 output tiles) and pay for it in fp32 atomics (3.6 x the algorithmic traffic); together the ~650 tiles of a block
+// are 2.5 rounds of workgroups, so most tiles run WHOLE (plain read-add-store into the gradient sink) and only a tail is cut
+// into K slices (atomic adds) to level the last round.  Grid order = dispatch order: per problem its whole tiles first
+// (`unsplit` of them, XCD-aware raster inside the problem), then per problem the slices of its remaining tiles.
+struct GroupProblem {
+    const bf16_t* A;       // dY [tokens][N]  (k-major "A": output rows = N)
+    const bf16_t* B;       // X  [tokens][K]  (k-major "B": output cols = K)
+    float* C;              // dW [N][K] fp32, accumulated into
+    int64_t lda, ldb, ldc;
+    int M, N, K;           // GEMM view: M = rows of dW, N = cols of dW, K = tokens
+    int tiles_m, tiles_n, group_m;
+    int unsplit, splits;   // tiles [0, unsplit) run whole; the others in `splits` K slices each
+    int r1_start, r2_start;   // first block id of this problem in the whole-tile region / the sliced region
+};
+struct GroupParams {
+    int nprob, r2_base;
+    GroupProblem pr[KALLE_MAX_GROUP];
+};
+
+__global__ __launch_bounds__(512, 2) void gemm3_wgrad_group_kernel(GroupParams gp) {
+    // blocks b, b + 8, ... share an XCD (and its L2): give every XCD a contiguous run of each region's work order, so that
+    // the ~32 tiles it runs at a time are neighbours in a problem's grouped raster and share operand panels through L2
+    const bool whole = (int)blockIdx.x < gp.r2_base;
+    const int bid = whole ? xcd_contiguous(blockIdx.x, gp.r2_base)
+                          : gp.r2_base + xcd_contiguous(blockIdx.x - gp.r2_base, gridDim.x - gp.r2_base);
+    int pi = 0, tile, slice = 0;
+    if (whole) {
+        while (pi + 1 < gp.nprob && bid >= gp.pr[pi + 1].r1_start) ++pi;
+        tile = bid - gp.pr[pi].r1_start;
+    } else {
+        while (pi + 1 < gp.nprob && bid >= gp.pr[pi + 1].r2_start) ++pi;
+        const int local = bid - gp.pr[pi].r2_start, nb = gp.pr[pi].tiles_m * gp.pr[pi].tiles_n - gp.pr[pi].unsplit;
+        tile = gp.pr[pi].unsplit + local % nb;
+        slice = local / nb;
+    }
+    const GroupProblem& q = gp.pr[pi];
+    GemmParams p{};
+    p.A = q.A; p.B = q.B; p.C = q.C;
+    p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+    p.M = q.M; p.N = q.N; p.K = q.K;
+    p.alpha = 1.f;
+    p.rows_per_batch = 1;
+    p.accumulate = 1;
+    p.atomic = whole ? 0 : 1;
+    const int ntiles = q.tiles_m * q.tiles_n, nk_all = (q.K + BK2 - 1) / BK2;
+    int tm, tn;
+    // raster: the whole tiles and the sliced tiles are each a contiguous run of the problem's grouped tile order
+    gemm_tile_coords_plain(tile, q.tiles_m, q.tiles_n, q.group_m, tm, tn);
+    (void)ntiles;
+    int kt0 = 0, nk = nk_all;
+    if (!whole) {
+        const int per = (nk_all + q.splits - 1) / q.splits;
+        kt0 = slice * per;
+        nk = min(per, nk_all - kt0);
+        if (nk <= 0) return;
+    }
+    gemm3_tile<true, true, true, 0>(p, tm, tn, kt0, nk);
 }
 
 template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
@@ -646,12 +749,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStream_t st) {
     p.mix_na = -1;
     p.mix_sa = 0;
-    if (p.K % BK2) return KALLE_ERR_UNSUPPORTED;
+    if (p.K & 7) return KALLE_ERR_UNSUPPORTED;        // (a ragged last K-tile is fine: K % 64 in multiples of 8)
     if (a_km && !b_km) return KALLE_ERR_UNSUPPORTED;
     if (a_km && !f32) return KALLE_ERR_UNSUPPORTED;
     if (p.M < 256 || p.N < 128) return KALLE_ERR_UNSUPPORTED;
     if (a_km && (p.M & 7)) return KALLE_ERR_UNSUPPORTED;
-    const int nk = p.K / BK2;
+    const int nk = (p.K + BK2 - 1) / BK2;
     if (p.glu_mode) {
         // fused SwiGLU: 256 x 256 kernel only; forward pairs x/gate weight rows inside each wave's 64 tile columns
         if (a_km || f32 || p.gate || p.residual || p.row_mask || p.c_rpb || p.accumulate) return KALLE_ERR_UNSUPPORTED;
@@ -837,4 +940,121 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
     p.tiles_n = (N + 127) / 128;
     g_last_plan = 1;
     return kalle_gemm_v1_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);
+}
+
+// ---- kalle_gemm_wgrad_group: host side -----------------------------------------------------------------------------------
+namespace {
+struct GroupPlan { uint64_t key; int ntot; int unsplit_total, splits; };
+
+// makespan (us) of a plan on 256 CUs: whole tiles first, then the slices; a slice costs 10 us + 1.6 us per K-tile (fitted to
+// tools/wgrad_sweep.py), atomics at 2 TB/s for the sliced tiles only
+double replay_group(const GroupProblem* pr, int n, int unsplit_total, int splits) {
+    double cu[256];
+    for (int c = 0; c < 256; ++c) cu[c] = 0.0;
+    auto put = [&](double d) {
+        std::pop_heap(cu, cu + 256, std::greater<double>());
+        cu[255] += d;
+        std::push_heap(cu, cu + 256, std::greater<double>());
+    };
+    int left = unsplit_total;
+    double atomic_bytes = 0.0;
+    int rest[KALLE_MAX_GROUP];
+    for (int i = 0; i < n; ++i) {
+        const int t = pr[i].tiles_m * pr[i].tiles_n, u = left < t ? left : t;
+        left -= u;
+        rest[i] = t - u;
+        const double d = 10.0 + 1.6 * ((pr[i].K + BK2 - 1) / BK2);
+        for (int k = 0; k < u; ++k) put(d);
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!rest[i]) continue;
+        const int nk = (pr[i].K + BK2 - 1) / BK2, per = (nk + splits - 1) / splits;
+        for (int sl = 0; sl < splits; ++sl) {
+            const int k = nk - sl * per < per ? nk - sl * per : per;
+            if (k <= 0) break;
+            for (int t = 0; t < rest[i]; ++t) put(10.0 + 1.6 * k);
+        }
+        if (splits > 1) atomic_bytes += (double)rest[i] * splits * 256.0 * 256.0 * 4.0;
+    }
+    double mk = 0.0;
+    for (int c = 0; c < 256; ++c) mk = cu[c] > mk ? cu[c] : mk;
+    return mk + atomic_bytes / 2.0e12 * 1e6;
+}
+}  // namespace
+
+extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, void* stream) {
+    if (!problems || nprob <= 0 || nprob > KALLE_MAX_GROUP) return KALLE_ERR_ARG;
+    GroupParams gp{};
+    gp.nprob = nprob;
+    int ntot = 0, min_nk = 1 << 30;
+    uint64_t key = 1469598103934665603ull;
+    for (int i = 0; i < nprob; ++i) {
+        const kalle_wgrad_problem& w = problems[i];
+        if (!w.dy || !w.x || !w.dw || w.N <= 0 || w.K <= 0 || w.tokens <= 0) return KALLE_ERR_ARG;
+        if ((w.N & 7) || (w.K & 7) || (w.lddy & 7) || (w.ldx & 7) || (w.lddw & 3)) return KALLE_ERR_ARG;
+        if (!al16(w.dy) || !al16(w.x) || !al16(w.dw)) return KALLE_ERR_ARG;
+        if (w.tokens & 7) return KALLE_ERR_UNSUPPORTED;       // (the caller falls back to one kalle_gemm_bf16 per gradient)
+        GroupProblem& q = gp.pr[i];
+        q.A = static_cast<const bf16_t*>(w.dy); q.B = static_cast<const bf16_t*>(w.x); q.C = w.dw;
+        q.lda = w.lddy; q.ldb = w.ldx; q.ldc = w.lddw;
+        q.M = w.N; q.N = w.K; q.K = w.tokens;
+        q.tiles_m = (q.M + 255) / 256; q.tiles_n = (q.N + 255) / 256;
+        q.group_m = q.tiles_m < 4 ? q.tiles_m : 4;
+        ntot += q.tiles_m * q.tiles_n;
+        min_nk = (q.K + BK2 - 1) / BK2 < min_nk ? (q.K + BK2 - 1) / BK2 : min_nk;
+        for (uint64_t v : {(uint64_t)w.N, (uint64_t)w.K, (uint64_t)(w.tokens / 1024)}) key = (key ^ v) * 1099511628211ull;
+    }
+    // plan: how many tiles run whole (a multiple of the 256 CUs, or all) and into how many slices the others are cut
+    static thread_local GroupPlan cache[16];
+    static thread_local int ncache = 0, victim = 0;
+    const GroupPlan* hit = nullptr;
+    for (int i = 0; i < ncache; ++i)
+        if (cache[i].key == key && cache[i].ntot == ntot) hit = &cache[i];
+    GroupPlan plan{key, ntot, ntot, 1};
+    static const char* env_plan = getenv("KALLE_WGRAD_GROUP_PLAN");      // "unsplit,splits": experiment override
+    if (env_plan && sscanf(env_plan, "%d,%d", &plan.unsplit_total, &plan.splits) == 2) {
+        plan.unsplit_total = plan.unsplit_total < ntot ? (plan.unsplit_total < 0 ? 0 : plan.unsplit_total) : ntot;
+        plan.splits = plan.splits < 1 ? 1 : plan.splits;
+    } else if (hit) {
+        plan = *hit;
+    } else {
+        double best = 1e30;
+        for (int u = 0;; u += 256) {
+            const int ut = u < ntot ? u : ntot;
+            for (int sp = 1; sp <= 12 && (sp == 1 || min_nk / sp >= 8); ++sp) {
+                if (ut == ntot && sp > 1) break;
+                const double t = replay_group(gp.pr, nprob, ut, sp);
+                if (t < best * 0.995) { best = t; plan.unsplit_total = ut; plan.splits = sp; }
+            }
+            if (ut == ntot) break;
+        }
+        if (ncache < 16) cache[ncache++] = plan;
+        else { cache[victim] = plan; victim = (victim + 1) & 15; }
+    }
+    if (min_nk / plan.splits < 1) plan.splits = 1;
+    int left = plan.unsplit_total, b1 = 0;
+    for (int i = 0; i < nprob; ++i) {
+        GroupProblem& q = gp.pr[i];
+        const int t = q.tiles_m * q.tiles_n;
+        q.unsplit = left < t ? left : t;
+        left -= q.unsplit;
+        q.splits = plan.splits;
+        q.r1_start = b1;
+        b1 += q.unsplit;
+    }
+    gp.r2_base = b1;
+    int b2 = b1;
+    for (int i = 0; i < nprob; ++i) {
+        GroupProblem& q = gp.pr[i];
+        q.r2_start = b2;
+        b2 += (q.tiles_m * q.tiles_n - q.unsplit) * q.splits;
+    }
+    static const bool dbg = getenv("KALLE_GEMM_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[kalle wgrad group] %d problems, %d tiles: %d whole + %d x %d slices = %d workgroups\n", nprob, ntot,
+                     b1, ntot - b1, plan.splits, b2);
+    constexpr int lds = 2 * (256 + 256) * 128;
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm3_wgrad_group_kernel), lds, lds_ok);
+    KALLE_LAUNCH(gemm3_wgrad_group_kernel, dim3(b2), dim3(512), lds, static_cast<hipStream_t>(stream), gp);
+    return kalle_check_launch();
 }

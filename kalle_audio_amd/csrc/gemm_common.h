@@ -48,6 +48,23 @@ __device__ __forceinline__ void gemm_tile_coords(int bid, int nwg, int tiles_m, 
     tn = in / gsz;
 }
 
+// block id -> position in the work order such that the blocks of one XCD (ids b, b + 8, ...) cover a contiguous run of it
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+    const int qd = nwg >> 3, rm = nwg & 7, xcd = bid & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+}
+
+// the grouped raster alone (workgroup ids of a grouped launch are not a multiple of 8 per problem: no XCD remap there)
+__device__ __forceinline__ void gemm_tile_coords_plain(int wg, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    const int per_group = gm * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * gm;
+    const int gsz = min(gm, tiles_m - first_m);
+    const int in = wg - group * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
 // logical output row -> stored row (project_in writes behind the prepended tokens of the residual stream)
 __device__ __forceinline__ int64_t gemm_crow(const GemmParams& p, int gm) {
     return p.c_rpb > 0 ? (int64_t)(gm / p.c_rpb) * p.c_brows + p.c_roff + gm % p.c_rpb : gm;

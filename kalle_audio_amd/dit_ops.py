@@ -16,6 +16,8 @@ from . import ops
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+import os as _os
+GROUP_WGRAD = _os.environ.get("KALLE_GROUP_WGRAD", "1") != "0"     # all weight gradients of a block in one launch
 
 
 def bf16_of(p):
@@ -52,12 +54,41 @@ class GradOut:
         self.accumulate = accumulate
         self.prefix = prefix
         self.grads = {}
+        self.deferred = None            # list of (name, dy, x) while a block's weight gradients are being collected
 
     def _sink(self, name):
         return self.sinks.get(self.prefix + name)
 
+    def defer(self):
+        """collect the weight gradients of a block and launch them together in flush() (kalle_gemm_wgrad_group)"""
+        if GROUP_WGRAD:
+            self.deferred = []
+        return self
+
+    def flush(self):
+        items, self.deferred = self.deferred, None
+        if not items:
+            return
+        probs = []
+        for name, dy, x in items:
+            s = self._sink(name)
+            if s is not None:
+                if not self.accumulate:
+                    s.zero_()
+                out = s
+                self.grads[name] = None
+            else:
+                out = self.grads[name] = torch.zeros((dy.shape[1], x.shape[1]), device=dy.device, dtype=F32)
+            probs.append((dy, x, out))
+        if not ops.gemm_wgrad_group(probs):        # shapes outside the grouped kernel: one GEMM each, accumulating
+            for dy, x, out in probs:
+                ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=True)
+
     def wgrad(self, name, dy, x):
         """dW[N,K] = dy[M,N]^T @ x[M,K]"""
+        if self.deferred is not None and dy.shape[0] % 8 == 0 and dy.is_contiguous() and x.is_contiguous():
+            self.deferred.append((name, dy, x))
+            return
         s = self._sink(name)
         if s is not None:
             ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=self.accumulate)
@@ -280,7 +311,7 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
     producer - the next block's LayerNorm backward - emitted them).  Returns (dx fp32, dctx fp32|None,
     dglobal fp32|None, go, dx bf16|None)."""
     D = g.shape[-1]
-    go = go or GradOut()
+    go = (go or GradOut()).defer()
     ada = sv.ada
     mod = sv.mod if ada else None
     sl = (lambda i: mod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
@@ -331,4 +362,5 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         go.wgrad("to_scale_shift_gate.1.weight", dmb, sv.sgb)
         dsg = dgrad(dmb, p.wmod, out_dtype=F32)
         dglobal = ops.silu_bwd(dsg, sv.x_global)
+    go.flush()
     return dx, dctx, dglobal, go, dxb

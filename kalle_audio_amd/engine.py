@@ -268,7 +268,9 @@ class DataParallelTrainer:
         # that writes its output whole would have to read the cleared buffer back instead (B = 16: -5 %), so small
         # micro-batches keep the overwrite-on-first-micro-batch rule.
         rows = max((getattr(blk, "_kalle_last_rows", 0) for _, blk in self.blocks), default=0)
-        clear_once = rows >= 8192
+        # (the grouped weight-gradient launch of a block always accumulates into the sinks: one clear serves it too)
+        from . import dit_ops
+        clear_once = rows >= 8192 or (dit_ops.GROUP_WGRAD and rows > 0 and rows % 8 == 0)
         for _, blk in self.blocks:
             blk._kalle_grad_accumulate = True if clear_once else not first
         if first:

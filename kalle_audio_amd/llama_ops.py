@@ -80,7 +80,7 @@ def layer_fwd(p, x, B, L, rope, mask8):
 def layer_bwd(p, saved, g, B, L, rope, mask8, go=None, g_bf16=None, want_dx_bf16=False):
     """g: fp32 [B*L, D] gradient of the layer output (g_bf16: its bf16 copy if the layer above left one).
     Returns (dx fp32, dx bf16 | None, go)."""
-    go = go or GradOut()
+    go = (go or GradOut()).defer()          # the four weight gradients of the layer go out in one grouped launch
     x, h1, rr1, qkv, ao, lse, x2, h2, rr2, hf, act = saved
     H, Hkv = p.H, p.Hkv
     D = H * 64
@@ -107,6 +107,7 @@ def layer_bwd(p, saved, g, B, L, rope, mask8, go=None, g_bf16=None, want_dx_bf16
     dh1 = dgrad(dqkv, p.wqkv)
     dxb = torch.empty((M, D), device=g.device, dtype=BF16) if want_dx_bf16 else None
     dx = go.rms("input_layernorm.weight", dh1, x, p.g1, rr1, dres=dx2, dx_bf16=dxb)
+    go.flush()
     return dx, dxb, go
 
 

@@ -111,7 +111,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
         variant = "%s<%d,%d,%d%s>" % (kname, int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32),
                                       ",glu%d" % glu_mode if glu_mode else "")      # (the fused-SwiGLU kernels are their own rows)
         abytes = 2.0 * (M * K + N * K) + M * N * out.element_size() + (4.0 * M * N if residual is not None else 0.0)
-        prof.append((variant, 2.0 * M * N * K, e0, e1, abytes))
+        prof.append((variant, 2.0 * M * N * K, e0, e1, abytes, (M, N, K)))
     return out
 
 
@@ -517,3 +517,39 @@ def segment_copy(src, dst, src_off, dst_off, lens, nbatch, rows, *, src_strides,
                                      src_strides[2], dst_strides[0], dst_strides[1], dst_strides[2], _stream()),
               "kalle_segment_copy")
     return dst
+
+
+MAX_GROUP = 8
+
+
+def gemm_wgrad_group(problems):
+    """problems: list of (dy bf16 [tokens, N], x bf16 [tokens, K], dw fp32 [N, K]); dw += dy^T x for all of them in one launch
+    per 8.  Returns False (nothing launched) when the shapes are outside the grouped kernel's domain."""
+    lib = _lib.load()
+    for dy, x, dw in problems:
+        if dy.shape[0] % 8 or dy.shape[0] != x.shape[0] or dy.shape[1] % 8 or x.shape[1] % 8:
+            return False
+        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+        assert dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1
+    prof = KERNEL_TIMER
+    for g in range(0, len(problems), MAX_GROUP):
+        grp = problems[g:g + MAX_GROUP]
+        arr = (_lib.WgradProblem * len(grp))()
+        flops = abytes = 0.0
+        for w, (dy, x, dw) in zip(arr, grp):
+            w.dy, w.lddy, w.x, w.ldx, w.dw, w.lddw = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
+            w.N, w.K, w.tokens = dy.shape[1], x.shape[1], dy.shape[0]
+            _p(dy), _p(x), _p(dw)                                     # (CPU tensors raise)
+            flops += 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
+            abytes += 2.0 * dy.shape[0] * (dy.shape[1] + x.shape[1]) + 8.0 * dy.shape[1] * x.shape[1]
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = lib.kalle_gemm_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(grp), _stream())
+        if rc == -3 and g == 0:
+            return False
+        check(rc, "kalle_gemm_wgrad_group")
+        if prof is not None:
+            e1.record()
+            prof.append(("gemm3_wgrad_group_kernel", flops, e0, e1, abytes, (len(grp), 0, grp[0][0].shape[0])))
+    return True

@@ -634,3 +634,52 @@ def test_rccl_path_world1_forced_comm(dev, tmp_path):
         assert sm["backend"] == "nccl" and sm["ranks"] == 1 and sm["allreduce_active"] and sm["buckets_per_step"] == 3, sm
         assert sm["exposed_ms_per_step"] >= 0.0
     assert res["accum_events"] == 2
+
+
+# ------------------------------------------------------------------------------------------------ grouped weight gradients
+@pytest.mark.parametrize("tokens,shapes", [(512, [(4096, 4096), (512, 256), (264, 136)]),     # 256 whole tiles + a sliced tail
+                                           (4096, [(512, 384), (256, 640), (128, 128)]),      # few tiles: all cut into K slices
+                                           (8064, [(1536, 1536), (4608, 1536), (1536, 768)]),
+                                           (2016, [(1536, 1536), (4608, 1536), (1536, 768)])])   # B = 16: ragged last K-tile
+def test_grouped_wgrad_kernel_vs_fp32(dev, tokens, shapes):
+    """kalle_gemm_wgrad_group: several dW += dY^T X problems in one launch (whole tiles: read-add-store; sliced tiles: atomics)
+    against an fp32 matmul of the same bf16 operands, accumulating onto a non-zero sink; and against one kalle_gemm_bf16 each"""
+    from kalle_audio_amd import ops
+    g = torch.Generator().manual_seed(tokens)
+    probs, refs, singles = [], [], []
+    for n, k in shapes:
+        dy = (torch.randn(tokens, n, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+        x = torch.randn(tokens, k, generator=g).to(dev).to(torch.bfloat16)
+        base = torch.randn(n, k, generator=g).to(dev)
+        probs.append((dy, x, base.clone()))
+        refs.append(base.double() + dy.double().T @ x.double())
+        singles.append(base + ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32))
+    assert ops.gemm_wgrad_group(probs)
+    torch.cuda.synchronize()
+    for (dy, x, out), ref, one in zip(probs, refs, singles):
+        assert rel(out, ref.float()) < 2e-5, rel(out, ref.float())          # fp32 accumulation of exact bf16 products
+        assert rel(out, one) < 2e-5
+    assert not ops.gemm_wgrad_group([(probs[0][0][:100], probs[0][1][:100], probs[0][2])])   # tokens % 8: caller falls back
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 384, 200), (2016, 1536, 1544), (304, 256, 72)])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tt"])
+def test_gemm_ragged_k_on_the_lds_dma_kernels(dev, M, N, K, layout):
+    """K not a multiple of 64 (B = 16 per GPU gives 2016-token weight gradients): the 256-wide LDS-DMA kernels take the missing
+    pieces of the last K-tile from a block of zeros; result = fp32 matmul of the bf16 operands.  The memory behind the
+    operands is poisoned with NaN so that any read past K shows."""
+    from kalle_audio_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a_km, b_km = layout == "tt", layout in ("nt", "tt")
+    def operand(rows, cols):                                 # a [rows, cols] view at the START of a NaN-filled buffer
+        buf = torch.full((rows + 64, cols), float("nan"), device=dev, dtype=torch.bfloat16)
+        buf[:rows] = torch.randn(rows, cols, generator=g).to(dev).to(torch.bfloat16)
+        return buf[:rows]
+    a = operand(K, M) if a_km else operand(M, K)
+    b = operand(K, N) if b_km else operand(N, K)
+    A = a.double().T if a_km else a.double()
+    Bm = b.double() if b_km else b.double().T
+    ref = (A @ Bm).float()
+    out = ops.gemm(a, b, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 2e-5, rel(out, ref)
