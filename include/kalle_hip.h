@@ -266,7 +266,9 @@ int kalle_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * tap are one aligned scalar load (once per forward; weights are frozen in every reference script, factory.py:77-80):
  *   transposed=0 (Conv1d):          v [Cout=d0][Cin=d1][K], g [Cout] -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co,:,:]||
  *   transposed=1 (ConvTranspose1d): v [Cin=d0][Cout=d1][K], g [Cin]  -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci,:,:]||
- *   g == NULL: repack only (plain nn.Conv1d).   (dac.nn.layers.WNConv1d -> torch weight_norm; autoencoders.py:9) */
+ *   g == NULL: repack only (plain nn.Conv1d).   (dac.nn.layers.WNConv1d -> torch weight_norm; autoencoders.py:9)
+ *   transposed | 2: additionally store tap k at K-1-k - with transposed=1 on a Conv1d's (v, g) this is the weight of the
+ *   convolution that computes the DATA gradient of a stride-1 conv (kalle_conv1d_fwd over dy, padding (K-1)*dil - pad). */
 int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                            int transposed, void* stream);
 /* activation descriptor of the conv kernels.  code: 0 none, 1 Snake / SnakeBeta x + sin^2(a x)/(b + 1e-9) with per-channel
@@ -326,7 +328,8 @@ int kalle_conv_transpose1d_cfirst_fwd(const float* x_padded, const float* w_pack
                                       int Cin, int Lp, int Cout, int Lout, int ksize, int stride, int padding,
                                       const kalle_conv_epilogue* epi, void* stream);
 /* y = epilogue(conv_transpose1d(in_act(x), w, b, stride, padding))   (autoencoders.py:98-100 DecoderBlock);
- * Lout may be shorter than the full length: the causal variant trims the last `stride` outputs (backup/flows.py:383-384) */
+ * Lout may be shorter than the full length: the causal variant trims the last `stride` outputs (backup/flows.py:383-384);
+ * and up to `padding` longer (outputs the symmetric right trim would drop: the data gradient of a strided conv) */
 int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const float* w_packed, const float* bias, void* y,
                                int y_dtype, int B, int Cin, int Lin, int Cout, int Lout, int ksize, int stride,
                                int padding, const kalle_act* in_act, const kalle_conv_epilogue* epi, void* stream);
@@ -395,6 +398,32 @@ int kalle_gauss_kl2_fwd(const float* pred, const float* label_mean, const float*
 int kalle_gauss_kl2_bwd(const float* pred, const float* label_mean, const float* label_std, int label_mode, float std_mult,
                         const float* mask_a, const float* mask_b, const float* sums4, const float* grad_a,
                         const float* grad_b, float* dpred, int64_t rows, int dim, void* stream);
+
+/* ---- backward of the VAE conv stacks (training the pretransform: `enable_grad`, models/factory.py:77-80; the reference
+ * leaves it to torch autograd).  A fused forward unit is y = conv(act(x)) (+ residual) (-> tanh).
+ * Data gradient: the forward entry points over dy with weights re-packed by kalle_weight_norm_fold -
+ *   stride-1 Conv1d:   kalle_conv1d_fwd(dy, fold(v, g, 1 | 2), K, stride 1, padding (K-1)*dil - pad, dil)
+ *   strided Conv1d:    kalle_conv_transpose1d_fwd(dy, fold(v, g, 1), K, stride, padding)
+ *   ConvTranspose1d:   kalle_conv1d_fwd(dy, fold(v, g, 0), K, stride, padding)
+ * Weight gradient (fp32, position reduction on the vector ALU, added atomically into dW which the caller zeroes):
+ *   dW[cu][cv][k] += sum_{b, m} U[b, cu, m] * V[b, cv, m*stride - padding + k*dilation]
+ *   Conv1d: U = dy [B][Cout][Lout], V = x [B][Cin][Lin]  -> dW in the module's [Cout][Cin][K] layout (act_on 0)
+ *   ConvTranspose1d: U = x [B][Cin][Lin], V = dy [B][Cout][Lout] -> dW [Cin][Cout][K]            (act_on 1)
+ *   `act` (code 0 / 1 SnakeBeta / 2 ELU) is the conv's INPUT activation, applied on the fly to x = V (act_on 0) or U (1). */
+int kalle_conv_wgrad(const float* U, const float* V, float* dW, int B, int CU, int CV, int MU, int LV, int ksize, int stride,
+                     int padding, int dilation, int act_on, const kalle_act* act, void* stream);
+/* dx = g * act'(x) for x, g [B][C][L] fp32; SnakeBeta (blocks.py:301-339) also adds d alpha, d beta [C] atomically
+ * (through the exp when logscale); act codes 0 / 1 / 2 */
+int kalle_act_bwd(const float* x, const float* g, float* dx, const kalle_act* act, float* dalpha, float* dbeta, int B, int C,
+                  int L, void* stream);
+/* g = dy * (1 - y^2): the decoder's final tanh (autoencoders.py:185) */
+int kalle_tanh_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream);
+/* out[c] += sum_{b, l} x[b][c][l]  (bias gradient; out zeroed or accumulated by the caller) */
+int kalle_channel_sum(const float* x, float* out, int B, int C, int L, void* stream);
+/* torch weight_norm (dim 0) backward: w = g v / ||v|| per slice of dim 0 (n = elements per slice):
+ * dg = <dw, v> / ||v||, dv = g / ||v|| (dw - v <dw, v> / ||v||^2); accumulate != 0 adds to dv / dg */
+int kalle_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int d0, int n,
+                          int accumulate, void* stream);
 
 /* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
  * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)

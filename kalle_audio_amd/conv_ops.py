@@ -81,7 +81,8 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
 
 def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alpha=None, beta=None, logscale=True,
                      out_dtype=None, trim=0, act_param=0.0, post_act=None, want_raw=False):
-    """trim: drop the last `trim` outputs (causal transposed conv)"""
+    """trim: drop the last `trim` outputs (causal transposed conv); negative: keep up to `padding` outputs beyond the symmetric
+    right trim (data gradient of a strided conv)"""
     lib = _lib.load()
     x = x.contiguous()
     B, Cin, Lin = x.shape
@@ -93,7 +94,8 @@ def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alph
     want = os.environ.get("KALLE_CONV_CFIRST")
     nq = (Lout - 1 + padding) // stride + 1
     small = ((nq + 511) // 512) * ((Cout + 63) // 64) * B * stride < 1024 and Cout >= 256
-    if act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32 and (want == "1" or (want is None and small)):
+    if (trim >= 0 and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
+            and (want == "1" or (want is None and small))):
         Lp = lib.kalle_convT_pad_len(Lout, K, stride, padding)
         xp = torch.empty((B, Cin, Lp), device=x.device, dtype=torch.float32)
         check(lib.kalle_conv_pad_act(_p(x), _p(xp), B, Cin, Lin, Lp, (K + stride - 1) // stride - 1, ctypes.addressof(ia), 1,

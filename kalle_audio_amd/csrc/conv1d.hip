@@ -800,8 +800,9 @@ __global__ __launch_bounds__(256) void cfirst_finish_kernel(ConvCParams p) {
 //   conv:  v [Cout][Cin][K], g [Cout]  -> w[ci][k][co] = g[co] v[co][ci][k] / ||v[co]||
 //   convT: v [Cin][Cout][K], g [Cin]   -> w[ci][k][co] = g[ci] v[ci][co][k] / ||v[ci]||
 __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ v, const float* __restrict__ g,
-                                                      float* __restrict__ w, int d0, int d1, int K, int transposed) {
+                                                      float* __restrict__ w, int d0, int d1, int K, int flags) {
     __shared__ float red[16];
+    const int transposed = flags & 1, flip = flags & 2;     // flip: tap k stored at K-1-k (the data gradient of a stride-1 conv)
     const int o = blockIdx.x;
     const int per = d1 * K;
     const int cout = transposed ? d1 : d0, coutp = (cout + 7) & ~7;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void wn_fold_kernel(const float* __restrict__ 
         scale = g[o] / sqrtf(s);
     }
     for (int i = threadIdx.x; i < per; i += 256) {
-        const int j = i / K, k = i - j * K;
+        const int j = i / K, k0 = i - j * K, k = flip ? K - 1 - k0 : k0;
         if (!transposed) {  // o = co, j = ci ; Cout = d0
             w[((int64_t)j * K + k) * coutp + o] = vp[i] * scale;
         } else {            // o = ci, j = co ; Cout = d1
@@ -946,7 +947,7 @@ extern "C" int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* f
 extern "C" int kalle_weight_norm_fold(const float* v, const float* g, float* w_packed, int d0, int d1, int ksize,
                                       int transposed, void* stream) {
     if (!v || !w_packed || d0 <= 0 || d1 <= 0 || ksize <= 0) return KALLE_ERR_ARG;
-    KALLE_LAUNCH(wn_fold_kernel, dim3(transposed ? d0 : ((d0 + 7) & ~7)), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
+    KALLE_LAUNCH(wn_fold_kernel, dim3((transposed & 1) ? d0 : ((d0 + 7) & ~7)), dim3(256), 0, static_cast<hipStream_t>(stream), v, g, w_packed, d0, d1,
                        ksize, transposed);
     return kalle_check_launch();
 }
@@ -1177,7 +1178,9 @@ extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const floa
                                           const kalle_conv_epilogue* epi, void* stream) {
     if (!x || !w_packed || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lout <= 0) return KALLE_ERR_ARG;
     if (ksize <= 0 || stride <= 0 || padding < 0) return KALLE_ERR_ARG;
-    if (Lout > (Lin - 1) * stride - 2 * padding + ksize) return KALLE_ERR_ARG;   // shorter = causal trim of the tail
+    // shorter than (Lin-1)*stride - 2*padding + K = causal trim of the tail; up to `padding` longer = the outputs the symmetric
+    // trim would drop on the right (the data gradient of a strided conv whose input length is not a multiple of the stride)
+    if (Lout > (Lin - 1) * stride - padding + ksize) return KALLE_ERR_ARG;
     if (B > 65535 || (Cout + 7) / 8 > 65535) return KALLE_ERR_ARG;
     ConvParams p{};
     if (!fill_params(p, in_act, epi)) return KALLE_ERR_ARG;

@@ -190,7 +190,8 @@ class DataParallelTrainer:
             for pre in prefixes:
                 if name.startswith(pre):
                     return pre
-            return "_rest"
+            # a pretransform trained with enable_grad (models/factory.py:77-80): its gradients travel in a bucket of their own
+            return "_vae" if name.startswith("pretransform.") or ".pretransform." in name else "_rest"
 
         # identical initial weights on every rank (rank 0 broadcasts), as DDP does at wrap time
         if self.world > 1:
@@ -231,7 +232,9 @@ class DataParallelTrainer:
 
     def _finish_comm(self):
         if self._boundary():
-            self._allreduce(self.flat.bucket_grad("_rest")) if "_rest" in self.flat.bucket_range else None
+            for key in ("_rest", "_vae"):
+                if key in self.flat.bucket_range:
+                    self._allreduce(self.flat.bucket_grad(key))
         timed = self.comm_timing is not None and self._pending and self.flat.grad.is_cuda
         if timed:
             # exposed (not overlapped) all-reduce time = how long the compute stream sits in the waits below: nothing is
@@ -276,8 +279,10 @@ class DataParallelTrainer:
         if first:
             if clear_once:
                 self.flat.grad.zero_()
-            elif "_rest" in self.flat.bucket_range:
-                self.flat.bucket_grad("_rest").zero_()     # autograd accumulates (+=) into these views
+            else:
+                for key in ("_rest", "_vae"):
+                    if key in self.flat.bucket_range:
+                        self.flat.bucket_grad(key).zero_()     # autograd accumulates (+=) into these views
         loss.backward()
         self._finish_comm()
         if self._boundary():

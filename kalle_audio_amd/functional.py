@@ -471,4 +471,29 @@ class MSELossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         (diff,) = ctx.saved_tensors
-        return (diff * gl).to(ctx.odt), None, None, None
+        g = diff * gl
+        # (the target carries a gradient only when the latents do: a pretransform trained with enable_grad)
+        return g.to(ctx.odt), (-g if ctx.needs_input_grad[1] else None), None, None
+
+
+class DiffuseFn(torch.autograd.Function):
+    """x_t, target of training/diffusion.py:365-379 (kalle_diffuse_fwd); differentiable w.r.t. the latents for the
+    enable_grad pretransform case: v: dx = alpha g_xt - sigma g_tgt; rectified flow: dx = (1 - t) g_xt - g_tgt  ([B, C, T]
+    broadcast arithmetic, host-side glue like the reference's own)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, t, objective):
+        ctx.save_for_backward(t)
+        ctx.objective = objective
+        return ops.diffuse_fwd(x, noise, t, objective)
+
+    @staticmethod
+    def backward(ctx, g_xt, g_tgt):
+        (t,) = ctx.saved_tensors
+        import math
+        if ctx.objective == "v":
+            a, s = torch.cos(t * math.pi / 2)[:, None, None], torch.sin(t * math.pi / 2)[:, None, None]
+            dx = g_xt * a - g_tgt * s
+        else:
+            dx = g_xt * (1 - t)[:, None, None] - g_tgt
+        return dx, None, None, None

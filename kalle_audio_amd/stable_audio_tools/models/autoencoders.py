@@ -3,8 +3,9 @@ dac.nn.layers wrappers, line 9), get_activation (24-37), ResidualUnit (39-62), E
 (83-114), OobleckEncoder (116-147), OobleckDecoder (150-191), AudioAutoencoder (230-560, encode/decode and the
 chunked overlap-and-paste variants), create_{encoder,decoder,autoencoder}_from_config (611-731).
 State-dict keys match torch's old-style weight_norm (`weight_g`, `weight_v`, `bias`) and SnakeBeta (`alpha`, `beta`),
-i.e. Stable-Audio-Open checkpoints load unchanged.  Forward only (the VAE is frozen in every reference script,
-factory.py:77-80); all math runs in kalle_audio_amd/csrc/conv1d.hip.  DAC / SEANet / local-attention / diffusion
+i.e. Stable-Audio-Open checkpoints load unchanged.  Inference (the VAE is frozen in every reference script,
+factory.py:77-80) runs the fused kernels of kalle_audio_amd/csrc/conv1d.hip; when gradients are wanted (`enable_grad`) the
+same modules run as autograd units of kalle_audio_amd/conv_train.py (csrc/conv1d_bwd.hip).  DAC / SEANet / local-attention / diffusion
 autoencoders of the same file are other model families and are not built.
 """
 import math
@@ -22,6 +23,12 @@ def _prep(x):
     if not x.is_cuda:
         raise RuntimeError("kalle_audio_amd VAE modules run on an MI355X GPU only (no CPU fallback)")
     return x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
+
+
+def _wants_grad(module, x):
+    """the training path (autograd nodes of kalle_audio_amd/conv_train.py) instead of the fused inference path: gradients are
+    being recorded and either the input or one of the module's parameters wants one"""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
 def _act_args(act):
@@ -78,6 +85,10 @@ class WNConv1d(_WNBase):
     def forward(self, x, act=None, residual=None, post=0, post_act=None, want_raw=False):
         """want_raw: also return the value before `post_act` -> (activated, raw)"""
         x = _prep(x)
+        if _wants_grad(self, x) or (act is not None and _wants_grad(act, x)):
+            assert post_act is None and not want_raw, "fused output activations belong to the inference path"
+            from ... import conv_train
+            return conv_train.act_conv(x, self, act, residual=residual, tanh=bool(post & 1))
         code, a, b, ls = _act_args(act)
         return conv_ops.conv1d(x, self._packed(), self._bias(), Cout=self.out_channels, K=self.kernel_size,
                                stride=self.stride, padding=self.padding, dilation=self.dilation, act=code, alpha=a,
@@ -100,6 +111,10 @@ class WNConvTranspose1d(_WNBase):
 
     def forward(self, x, act=None, post_act=None, want_raw=False):
         x = _prep(x)
+        if _wants_grad(self, x) or (act is not None and _wants_grad(act, x)):
+            assert post_act is None and not want_raw, "fused output activations belong to the inference path"
+            from ... import conv_train
+            return conv_train.act_conv(x, self, act)
         code, a, b, ls = _act_args(act)
         return conv_ops.conv_transpose1d(x, self._packed(), self._bias(), Cout=self.out_channels,
                                          K=self.kernel_size, stride=self.stride, padding=self.padding, act=code,
@@ -141,6 +156,9 @@ class ResidualUnit(nn.Module):
         """x_act: layers[0](x) if the producer already stored it (then the k=7 conv stages its input without any activation
         work); dual: return (post_act(y), y) - the pair the next unit wants"""
         x = _prep(x)
+        if _wants_grad(self, x):        # training: two autograd units, raw tensors in between
+            h = self.layers[1](x, act=self.layers[0])
+            return self.layers[3](h, act=self.layers[2], residual=x)
         if x_act is not None:
             h = self.layers[1](x_act, post_act=self.layers[2])
         else:
@@ -164,6 +182,8 @@ class EncoderBlock(nn.Module):
     def forward(self, x, post_act=None, x_act=None, dual=False):
         """x_act = layers[0].layers[0](x) if the producer stored it; dual: the strided conv returns (post_act(y), y)"""
         ru = self.layers
+        if _wants_grad(self, x):
+            return ru[4](ru[2](ru[1](ru[0](x))), act=ru[3])
         xa, x = ru[0](x, post_act=ru[1].layers[0], x_act=x_act, dual=True)
         xa, x = ru[1](x, post_act=ru[2].layers[0], x_act=xa, dual=True)
         x = ru[2](x, post_act=self.layers[3], x_act=xa)
@@ -192,6 +212,9 @@ class DecoderBlock(nn.Module):
         # every unit's output is needed raw (skip path of the next unit) and activated (its first conv): the producers store
         # both, so no k=7 conv spends VALU time re-activating its input tile once per output-channel tile
         ru = self.layers
+        if _wants_grad(self, x):
+            assert not pre_activated
+            return ru[4](ru[3](ru[2](ru[1](x, act=ru[0]))))
         xa, x = ru[1](x, act=None if pre_activated else ru[0], post_act=ru[2].layers[0], want_raw=True)
         xa, x = ru[2](x, post_act=ru[3].layers[0], x_act=xa, dual=True)
         xa, x = ru[3](x, post_act=ru[4].layers[0], x_act=xa, dual=True)
@@ -219,6 +242,11 @@ class OobleckEncoder(nn.Module):
         n = len(self.layers)
         if n == 3:
             return self.layers[2](self.layers[0](x), act=self.layers[1])
+        if _wants_grad(self, x):
+            x = self.layers[0](x)
+            for i in range(1, n - 2):
+                x = self.layers[i](x)
+            return self.layers[n - 1](x, act=self.layers[n - 2])
         first_act = lambda i: self.layers[i].layers[0].layers[0]      # first activation of encoder block i
         xa, x = self.layers[0](x, post_act=first_act(1), want_raw=True)
         for i in range(1, n - 2):
@@ -252,6 +280,11 @@ class OobleckDecoder(nn.Module):
 
     def forward(self, x):
         n = len(self.layers)
+        if _wants_grad(self, x):
+            x = self.layers[0](x)
+            for i in range(1, n - 3):
+                x = self.layers[i](x)
+            return self.layers[n - 2](x, act=self.layers[n - 3], post=1 if isinstance(self.layers[n - 1], nn.Tanh) else 0)
         # every block starts with an activation whose only reader is that block's transposed conv: the producer's
         # store applies it (layers[i + 1].layers[0] for the next block, layers[n - 3] before the last conv)
         nxt = lambda i: self.layers[i + 1].layers[0] if i + 1 < n - 3 else self.layers[n - 3]

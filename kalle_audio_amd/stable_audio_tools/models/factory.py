@@ -34,9 +34,7 @@ def create_pretransform_from_config(pretransform_config, sample_rate):
                                            model_half=pretransform_config.get("model_half", False),
                                            iterate_batch=pretransform_config.get("iterate_batch", False),
                                            chunked=pretransform_config.get("chunked", False))
-    enable_grad = pretransform_config.get('enable_grad', False)
-    if enable_grad:
-        raise NotImplementedError("enable_grad pretransforms (VAE fine-tuning): the conv kernels are forward-only")
+    enable_grad = pretransform_config.get('enable_grad', False)     # (VAE fine-tuning: conv backward in csrc/conv1d_bwd.hip)
     pretransform.enable_grad = enable_grad
     pretransform.eval().requires_grad_(pretransform.enable_grad)
     return pretransform

@@ -39,14 +39,15 @@ class AutoencoderPretransform(Pretransform):
         self.num_quantizers = None
         self.codebook_size = None
 
-    @torch.no_grad()
+    # No torch.no_grad() here, as in the reference (pretransforms.py:50-75): the caller decides - the training wrapper runs
+    # encode under torch.set_grad_enabled(self.enable_grad) (training/diffusion.py:343-346).  A frozen VAE with an input that
+    # needs no gradient takes the fused inference kernels; otherwise the conv stacks run as autograd units (conv_train.py).
     def encode(self, x, **kwargs):
         if self.model_half:
             x = x.to(torch.bfloat16)
         encoded = self.model.encode_audio(x, chunked=self.chunked, iterate_batch=self.iterate_batch, **kwargs)
         return encoded.float() / self.scale
 
-    @torch.no_grad()
     def decode(self, z, **kwargs):
         z = z * self.scale
         if self.model_half:

@@ -18,7 +18,11 @@ def diffusion_train_step(diffusion, latents, t, noise, cond, objective="v", cfg_
                          losses=None):
     """training/diffusion.py:365-399 given t and noise. Returns (loss, info)."""
     latents = latents.float().contiguous()
-    x_t, targets = ops.diffuse_fwd(latents, noise.float().contiguous(), t.float().contiguous(), objective)
+    if latents.requires_grad:       # a pretransform trained with enable_grad: the loss reaches the VAE through x_t and target
+        from ... import functional as KF
+        x_t, targets = KF.DiffuseFn.apply(latents, noise.float().contiguous(), t.float().contiguous(), objective)
+    else:
+        x_t, targets = ops.diffuse_fwd(latents, noise.float().contiguous(), t.float().contiguous(), objective)
     extra = {"mask": padding_mask} if padding_mask is not None else {}
     output = diffusion(x_t, t, cond=cond, cfg_dropout_prob=cfg_dropout_prob, **extra)
     if losses is None:
@@ -81,7 +85,8 @@ class DiffusionCondTrainingWrapper(nn.Module):
             padding_masks = torch.stack([md["padding_mask"][0] for md in metadata], dim=0).to(self.device)
         if self.diffusion.pretransform is not None:
             if not self.pre_encoded:
-                diffusion_input = self.diffusion.pretransform.encode(diffusion_input)
+                with torch.set_grad_enabled(bool(getattr(self.diffusion.pretransform, "enable_grad", False))):   # :343-346
+                    diffusion_input = self.diffusion.pretransform.encode(diffusion_input)
                 if use_padding_mask:
                     padding_masks = torch.nn.functional.interpolate(
                         padding_masks.unsqueeze(1).float(), size=diffusion_input.shape[2], mode="nearest").squeeze(1).bool()

@@ -44,7 +44,7 @@ class MSELoss(LossModule):
                 mask = mask[:, 0]
         if a.ndim != 3:
             raise NotImplementedError("MSELoss kernel expects (B, C, T) tensors")
-        return KF.MSELossFn.apply(a, b.detach(), mask, float(self.weight))
+        return KF.MSELossFn.apply(a, b, mask, float(self.weight))     # (the target's gradient exists only with enable_grad)
 
 
 class MultiLoss(nn.Module):

@@ -352,7 +352,49 @@ def chunked_vae():
     save("chunked_vae", **out)
 
 
-ALL = dict(chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
+def vae_backward():
+    """torch autograd of the reference's Oobleck pieces (what `enable_grad` pretransforms train with, models/factory.py:77-80):
+    ResidualUnit (dilated k=7 + k=1, residual), EncoderBlock (strided conv), DecoderBlock (transposed conv), and the whole
+    encode -> decode chain with the final tanh, SnakeBeta and ELU variants - input gradients in full, parameter gradients
+    (weight_g, weight_v, bias, alpha, beta) as 16-sample digests + a few in full"""
+    from stable_audio_tools.models import autoencoders as ra
+    from stable_audio_tools.models.factory import create_model_from_config
+    out = {}
+    B = 2
+    for snake in (True, False):
+        tag = "snake" if snake else "elu"
+        units = (("ru", ra.ResidualUnit(16, 16, dilation=3, use_snake=snake), 20, (B, 16, 200)),
+                 ("eb", ra.EncoderBlock(16, 32, stride=4, use_snake=snake), 21, (B, 16, 203)),
+                 ("db", ra.DecoderBlock(32, 16, stride=4, use_snake=snake), 22, (B, 32, 50)))
+        for name, mod, seed, shp in units:
+            load_seeded(mod, seed)
+            x = T(gu.make_input("x", shp, seed + 100, 1.0)).requires_grad_(True)
+            y = mod(x)
+            dy = T(gu.make_input("dy", tuple(y.shape), seed + 100))
+            y.backward(dy)
+            g = grads(mod)
+            out[f"{tag}/{name}/y"] = y
+            out[f"{tag}/{name}/dx"] = x.grad
+            out.update(digests(f"{tag}/{name}/", g, 16))
+            for k in list(g)[:3]:
+                out[f"{tag}/{name}/grad/{k}"] = g[k]
+        ae = load_seeded(create_model_from_config(gu.oobleck_cfg(snake)), 23)
+        ae.requires_grad_(True)
+        wav = T(gu.make_input("wav", (B, 2, 1200), 66, 0.5)).requires_grad_(True)
+        z = ae.encode(wav)
+        rec = ae.decode(z[:, :4] + 0.3 * z[:, 4:])
+        dz = T(gu.make_input("dz", tuple(z.shape), 66))
+        drec = T(gu.make_input("drec", tuple(rec.shape), 66))
+        ((z * dz).sum() + (rec * drec).sum()).backward()
+        g = grads(ae)
+        out[f"{tag}/ae/z"] = z
+        out[f"{tag}/ae/rec"] = rec
+        out[f"{tag}/ae/dwav"] = wav.grad
+        out.update(digests(f"{tag}/ae/", g, 16))
+    save("vae_backward", **out)
+
+
+ALL = dict(vae_backward=vae_backward, chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
            training_step=training_step, model_llasa=model_llasa)
 
 

@@ -528,3 +528,34 @@ def test_chunked_decode_fixture_is_consistent_with_oracle():
                 out[:, :, pos] = chunks[want[pos, 0]][:, :, want[pos, 1]]
             close(out, f[key], 1e-5)
     assert int(f["enc_chunked_runs"]) == 0       # the reference's chunked encode raises on its own pass-through bottleneck
+
+
+@pytest.mark.parametrize("snake", [True, False])
+def test_vae_backward(snake):
+    """autograd through the oracle's Oobleck restatement against the reference's torch autograd (the enable_grad case):
+    unit-level and whole encode -> decode gradients of weight_g / weight_v / bias / alpha / beta and of the input"""
+    f = fx("vae_backward")
+    tag = "snake" if snake else "elu"
+    Bv = 2
+    cases = (("ru", ko.residual_unit_shapes(16, snake), 20, (Bv, 16, 200), lambda sd, x: ko.residual_unit(sd, x, 3, snake)),
+             ("eb", ko.encoder_block_shapes(16, 32, 4, snake), 21, (Bv, 16, 203), lambda sd, x: ko.encoder_block(sd, x, 4, snake)),
+             ("db", ko.decoder_block_shapes(32, 16, 4, snake), 22, (Bv, 32, 50), lambda sd, x: ko.decoder_block(sd, x, 4, snake)))
+    for name, shapes, seed, shp, fn in cases:
+        sd = state(shapes, seed)
+        x = T(gu.make_input("x", shp, seed + 100, 1.0), True)
+        y = fn(sd, x)
+        close(y, f[f"{tag}/{name}/y"], 1e-5)
+        y.backward(T(gu.make_input("dy", tuple(y.shape), seed + 100)))
+        close(x.grad, f[f"{tag}/{name}/dx"], 2e-5)
+        check_digests_n(f, sd, 16, prefix=f"{tag}/{name}/", tol=1e-4)
+    vshapes = (ko.oobleck_encoder_shapes(2, 8, 8, [1, 2, 4], [2, 4, 5], snake, "encoder.") +
+               ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], snake, "decoder."))
+    sd = state(vshapes, 23)
+    wav = T(gu.make_input("wav", (Bv, 2, 1200), 66, 0.5), True)
+    z = ko.pretransform_encode(sd, wav, [2, 4, 5], snake)
+    rec = ko.pretransform_decode(sd, z[:, :4] + 0.3 * z[:, 4:], [2, 4, 5], snake, final_tanh=snake)
+    close(z, f[f"{tag}/ae/z"], 1e-5); close(rec, f[f"{tag}/ae/rec"], 1e-5)
+    dz, drec = T(gu.make_input("dz", tuple(z.shape), 66)), T(gu.make_input("drec", tuple(rec.shape), 66))
+    ((z * dz).sum() + (rec * drec).sum()).backward()
+    close(wav.grad, f[f"{tag}/ae/dwav"], 5e-5)
+    check_digests_n(f, sd, 16, prefix=f"{tag}/ae/", tol=2e-4)

@@ -683,3 +683,96 @@ def test_gemm_ragged_k_on_the_lds_dma_kernels(dev, M, N, K, layout):
     out = ops.gemm(a, b, a_kmajor=a_km, b_kmajor=b_km, out_dtype=torch.float32)
     assert torch.isfinite(out).all()
     assert rel(out, ref) < 2e-5, rel(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ VAE backward (enable_grad)
+@pytest.mark.parametrize("snake", [True, False])
+def test_vae_backward_units_and_chain(dev, snake):
+    """the conv stacks as autograd units (csrc/conv1d_bwd.hip + the forward kernels over dy): ResidualUnit, EncoderBlock,
+    DecoderBlock and encode -> decode against the reference's torch autograd; fp32 path, rel-L2 <= 1e-4 (2e-4 on the chain)"""
+    import kalle_audio_amd
+    kalle_audio_amd.install()
+    from stable_audio_tools.models import autoencoders as A
+    from stable_audio_tools.models.factory import create_model_from_config
+    f = fx("vae_backward")
+    tag = "snake" if snake else "elu"
+    Bv = 2
+    units = (("ru", A.ResidualUnit(16, 16, dilation=3, use_snake=snake), 20, (Bv, 16, 200)),
+             ("eb", A.EncoderBlock(16, 32, stride=4, use_snake=snake), 21, (Bv, 16, 203)),
+             ("db", A.DecoderBlock(32, 16, stride=4, use_snake=snake), 22, (Bv, 32, 50)))
+    for name, mod, seed, shp in units:
+        load_seeded(mod, seed, dev)
+        x = T(gu.make_input("x", shp, seed + 100, 1.0), dev, True)
+        y = mod(x)
+        assert rel(y, f[f"{tag}/{name}/y"]) < 1e-4, (name, rel(y, f[f"{tag}/{name}/y"]))
+        y.backward(T(gu.make_input("dy", tuple(y.shape), seed + 100), dev))
+        assert rel(x.grad, f[f"{tag}/{name}/dx"]) < 1e-4, (name, rel(x.grad, f[f"{tag}/{name}/dx"]))
+        g = {n: p.grad for n, p in mod.named_parameters()}
+        assert all(v is not None for v in g.values()), [n for n, v in g.items() if v is None]
+        check_digests(f, g, 16, prefix=f"{tag}/{name}/", tol=1e-3)
+        for k in f.files:
+            if k.startswith(f"{tag}/{name}/grad/"):
+                n = k[len(f"{tag}/{name}/grad/"):]
+                assert rel(g[n], f[k]) < 2e-4, (name, n, rel(g[n], f[k]))
+    ae = load_seeded(create_model_from_config(gu.oobleck_cfg(snake)), 23, dev)
+    ae.requires_grad_(True)
+    wav = T(gu.make_input("wav", (Bv, 2, 1200), 66, 0.5), dev, True)
+    z = ae.encode(wav)
+    rec = ae.decode(z[:, :4] + 0.3 * z[:, 4:])
+    assert rel(z, f[f"{tag}/ae/z"]) < 1e-4 and rel(rec, f[f"{tag}/ae/rec"]) < 1e-4
+    dz, drec = T(gu.make_input("dz", tuple(z.shape), 66), dev), T(gu.make_input("drec", tuple(rec.shape), 66), dev)
+    ((z * dz).sum() + (rec * drec).sum()).backward()
+    assert rel(wav.grad, f[f"{tag}/ae/dwav"]) < 2e-4, rel(wav.grad, f[f"{tag}/ae/dwav"])
+    check_digests(f, {n: p.grad for n, p in ae.named_parameters()}, 16, prefix=f"{tag}/ae/", tol=1e-3)
+    # frozen again: the same modules are back on the fused inference kernels (no autograd graph)
+    ae.requires_grad_(False)
+    with torch.no_grad():
+        z2 = ae.encode(wav.detach())
+    assert not z2.requires_grad and rel(z2, z) < 1e-5
+
+
+def test_training_step_with_enable_grad_pretransform(dev, monkeypatch):
+    """training_step with pretransform.enable_grad: the diffusion loss reaches the VAE encoder through x_t AND the target
+    (training/diffusion.py:343-346, 371-379); gradients against the CPU oracle's autograd on the same draws; and the trainer
+    gives the VAE parameters their own all-reduce bucket"""
+    from stable_audio_tools.training.diffusion import DiffusionCondTrainingWrapper
+    from kalle_audio_amd import engine
+    e = gu.E2E
+    seed, Bt = 62, e["B"]
+    f = fx("training_step")
+    model = _cond_model(dev, 8, "v", seed)
+    model.pretransform.enable_grad = True
+    model.pretransform.requires_grad_(True)
+    torch.manual_seed(1000 + seed)
+    wrap = DiffusionCondTrainingWrapper(model, lr=1e-4, mask_padding=False, use_ema=False, pre_encoded=False,
+                                        cfg_dropout_prob=0.0, timestep_sampler="uniform")
+    ctx, cm, gl = _e2e_cond(seed, "cpu")
+    wav = gu.make_input("wav", (Bt, 2, 40 * e["T"]), seed, 0.5)
+    meta = [{"prompt": ctx[b], "prompt_mask": cm[b], "g": gl[b]} for b in range(Bt)]
+    noise = T(f["v_uniform/noise"], dev)
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: noise.to(t.dtype))
+    loss = wrap.training_step((T(wav, dev), meta), 0)
+    loss.backward()
+    # oracle: same weights, same t (the Sobol draw of the fixture), same noise
+    from test_oracle_golden import e2e_states
+    sd_dit, sd_vae = e2e_states(8, seed, grad=False)
+    sd_vae = {k: v.clone().requires_grad_(True) for k, v in sd_vae.items()}
+    cfg = dict(embed_dim=e["D"], depth=2, num_heads=2, global_cond_type="prepend")
+    ci = ko.conditioning_inputs({"prompt": (ctx, cm), "g": (gl, None)}, ["prompt"], ["g"])
+    lat = ko.pretransform_encode(sd_vae, torch.from_numpy(wav), [2, 4, 5], True, 0.8)
+    lref, *_ = ko.train_step_loss(sd_dit, cfg, lat, torch.from_numpy(f["v_uniform/noise"]), torch.from_numpy(f["v_uniform/t"]),
+                                  "v", **ci)
+    lref.backward()
+    assert abs(loss.item() - lref.item()) < 1e-2 * lref.item()
+    n = 0
+    for name, p in model.pretransform.model.named_parameters():
+        if not name.startswith("encoder."):
+            continue
+        ref = sd_vae[name].grad
+        assert p.grad is not None, name
+        assert rel(p.grad, ref) < 5e-2, (name, rel(p.grad, ref))        # (through the bf16 DiT)
+        n += 1
+    assert n > 20
+    tr = engine.DataParallelTrainer(model, lr=1e-4)
+    assert "_vae" in tr.flat.bucket_keys
+    assert any(k.startswith("pretransform.") for k in tr.flat.names)
