@@ -8,8 +8,10 @@
  * (INTEGRATION.md shows the binding a maintainer would add on the reference side).
  *
  * Conventions: plain device pointers + sizes, `stream` is a hipStream_t passed as void*, every call
- * is asynchronous on that stream, allocates nothing, keeps no global state, and returns 0 on
- * success or a negative KALLE_ERR_* code (never throws).  bf16 tensors are raw uint16 storage.
+ * is asynchronous on that stream, allocates nothing, and returns 0 on success or a negative KALLE_ERR_* code (never
+ * throws).  Process state the library does keep: per-thread caches of GEMM split plans (pure functions of the shape), the
+ * calling thread's last plan / last HIP error name (kalle_gemm_last_plan, kalle_last_error), a per-kernel per-device flag for
+ * the dynamic-LDS attribute, and experiment switches read once from KALLE_* environment variables.  bf16 tensors are raw uint16 storage.
  */
 #ifndef KALLE_HIP_H
 #define KALLE_HIP_H
@@ -65,6 +67,13 @@ typedef struct kalle_gemm_epilogue {
     int32_t glu_inner;
     void* glu_aux;
     float* glu_dbias;
+    /* optional scratch for the few-rows path (sampling at generation batch sizes, small training batches): with
+     * workspace_bytes >= 8 * M * N the dispatcher may cut K into up to workspace_bytes / (4 M N) slices, each writing its
+     * partial result as an fp32 [M][N] slab (so that a GEMM with M <= 4096 rows fills 256 CUs), and sum the slabs in a fixed
+     * order + apply the epilogue in a finishing pass (bitwise reproducible).  The library never
+     * allocates: no workspace, no such path.  Contents are undefined afterwards; one workspace per stream. */
+    void* workspace;
+    int64_t workspace_bytes;
 } kalle_gemm_epilogue;
 
 int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,

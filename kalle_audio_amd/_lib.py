@@ -40,6 +40,8 @@ class GemmEpilogue(ctypes.Structure):
         ("glu_inner", ctypes.c_int32),
         ("glu_aux", ctypes.c_void_p),
         ("glu_dbias", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_int64),
     ]
 
 

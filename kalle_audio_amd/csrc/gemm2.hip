@@ -498,6 +498,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     if (kt + 1 < nk) { iteration(F_{}, T_{}, F_{}); ++kt; }
     iteration(F_{}, F_{}, F_{});
 
+    if constexpr (C_F32) {
+        if (p.slab_stride) {        // split-K into per-slice slabs (few-rows path)
+            GemmParams q = p;
+            q.C = static_cast<float*>(p.C) + (int64_t)blockIdx.y * p.slab_stride;
+            wave_epilogue<C_F32, TM>(q, acc, smem, wave, lane, m0 + arow, n0 + bcol);
+            return;
+        }
+    }
     wave_epilogue<C_F32, TM>(p, acc, smem, wave, lane, m0 + arow, n0 + bcol);
 }
 
@@ -890,6 +898,111 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     return launch2_layout<4, 2, 4>(p, a_km, b_km, f32, st);
 }
 
+// ---- few rows (M <= 4096): split-K into a caller-provided fp32 scratch + finishing pass -----------------------------------
+// A GEMM whose output has only a few 256-row tile rows cannot fill 256 CUs with output tiles: the DiT forward at generation
+// batch sizes (B = 1 with CFG: 252 rows) gives 12 - 96 tiles, a B = 16 train step 96 - 384.  K is cut into slices that add
+// their partial tiles as plain fp32 slabs [slice][M][N] into the caller's scratch; the finishing pass sums the slabs in slice order
+// (bitwise reproducible) and applies the whole epilogue (alpha, bias, adaLN gate, row mask, residual, accumulate, output-row
+// remap, fused SwiGLU forward) while writing C.
+namespace {
+template <bool C_F32>
+__global__ __launch_bounds__(256) void gemm_finish_kernel(GemmParams p, const float* __restrict__ ws, int nslab) {
+    const int64_t slab = (int64_t)p.M * p.N;
+    auto ld4 = [&](int64_t off) {               // sum of the K slices' partial results, always in slice order
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + off);
+        for (int s = 1; s < nslab; ++s) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ws + s * slab + off);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        return a;
+    };
+    const int cols4 = (p.glu_mode == 1 ? p.glu_inner : p.N) >> 2;
+    const int64_t total = (int64_t)p.M * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int gm = (int)(i / cols4), gn = (int)(i - (int64_t)gm * cols4) * 4;
+        if (p.glu_mode == 1) {
+            // fused SwiGLU forward (transformer.py:216-219): h = x W^T + b [M][2 inner] (bf16), act = h_x * silu(h_gate)
+            const f32x4 xv = ld4((int64_t)gm * p.N + gn);
+            const f32x4 gv = ld4((int64_t)gm * p.N + p.glu_inner + gn);
+            float x[4] = {xv[0], xv[1], xv[2], xv[3]}, g[4] = {gv[0], gv[1], gv[2], gv[3]};
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x[j] += p.bias[gn + j]; g[j] += p.bias[p.glu_inner + gn + j]; }
+            }
+            i32x2 hx, hg, av;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                hx[e] = (int)pack_bf16x2(x[2 * e], x[2 * e + 1]);
+                hg[e] = (int)pack_bf16x2(g[2 * e], g[2 * e + 1]);
+                const float x0 = bf16lo((uint32_t)hx[e]), x1 = bf16hi((uint32_t)hx[e]);
+                const float g0 = bf16lo((uint32_t)hg[e]), g1 = bf16hi((uint32_t)hg[e]);
+                av[e] = (int)pack_bf16x2(x0 * siluf_(g0), x1 * siluf_(g1));
+            }
+            bf16_t* hp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
+            *reinterpret_cast<i32x2*>(hp + gn) = hx;
+            *reinterpret_cast<i32x2*>(hp + p.glu_inner + gn) = hg;
+            *reinterpret_cast<i32x2*>(static_cast<bf16_t*>(p.glu_aux) + (int64_t)gm * p.glu_inner + gn) = av;
+            continue;
+        }
+        const f32x4 a = ld4((int64_t)gm * p.N + gn);
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        const int64_t crow = gemm_crow(p, gm);
+        gemm_epilogue4(p, gm, gn, crow, v, true);
+        if constexpr (C_F32) {
+            float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
+            if (p.accumulate) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += c0[j];
+            }
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            i32x2 o;
+            o[0] = (int)pack_bf16x2(v[0], v[1]);
+            o[1] = (int)pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<i32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
+        }
+    }
+}
+}  // namespace
+
+// returns KALLE_ERR_UNSUPPORTED when the shape is better served by the ordinary path (the caller goes on to it)
+int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool f32, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (a_km || !ws || pin.M > 4096 || (pin.K & 7) || (pin.N & 7)) return KALLE_ERR_UNSUPPORTED;
+    if (pin.glu_mode == 2 || (pin.glu_mode == 1 && (b_km || f32 || pin.N != 2 * pin.glu_inner || (pin.glu_inner & 3))))
+        return KALLE_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return KALLE_ERR_UNSUPPORTED;
+    const int nk = (pin.K + BK2 - 1) / BK2;
+    const int tiles = ((pin.M + 255) / 256) * ((pin.N + 127) / 128);
+    if (tiles >= 192) return KALLE_ERR_UNSUPPORTED;                 // enough output tiles on their own
+    int splits = (320 + tiles - 1) / tiles;                          // ~1.25 workgroups per CU
+    if (splits > nk / 2) splits = nk / 2;                            // at least two K-tiles per slice
+    const int64_t slab = (int64_t)pin.M * pin.N;
+    if (splits > ws_bytes / (4 * slab)) splits = (int)(ws_bytes / (4 * slab));   // one fp32 [M][N] slab per slice
+    if (splits < 2) return KALLE_ERR_UNSUPPORTED;
+    GemmParams q{};
+    q.A = pin.A; q.B = pin.B; q.C = ws;
+    q.lda = pin.lda; q.ldb = pin.ldb; q.ldc = pin.N;
+    q.M = pin.M; q.N = pin.N; q.K = pin.K;
+    q.alpha = 1.f;
+    q.rows_per_batch = 1;
+    q.tiles_m = (pin.M + 255) / 256; q.tiles_n = (pin.N + 127) / 128; q.tile_n = 128;
+    q.group_m = q.tiles_m < 4 ? q.tiles_m : 4;
+    q.atomic = 0;
+    q.mix_na = -1;
+    q.ktiles_per_split = (nk + splits - 1) / splits;
+    q.splits = (nk + q.ktiles_per_split - 1) / q.ktiles_per_split;
+    q.slab_stride = slab;
+    const int rc = b_km ? launch2<false, true, true, 4, 2, 4>(q, st) : launch2<false, false, true, 4, 2, 4>(q, st);
+    if (rc != KALLE_OK) return rc;
+    GemmParams f = pin;
+    const int64_t work = (int64_t)pin.M * ((pin.glu_mode == 1 ? pin.glu_inner : pin.N) >> 2);
+    const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    if (f32) KALLE_LAUNCH(gemm_finish_kernel<true>, dim3(grid), dim3(256), 0, st, f, static_cast<const float*>(ws), q.splits);
+    else KALLE_LAUNCH(gemm_finish_kernel<false>, dim3(grid), dim3(256), 0, st, f, static_cast<const float*>(ws), q.splits);
+    return kalle_check_launch();
+}
+
 static thread_local int g_last_plan = 0;
 extern "C" int kalle_gemm_last_plan(void) { return g_last_plan; }
 
@@ -928,6 +1041,13 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool f32 = c_dtype == KALLE_F32;
+    if (ep && ep->workspace && force_mode() != 1) {
+        const int rc = kalle_gemm_few_rows_launch(p, a_kmajor != 0, b_kmajor != 0, f32, ep->workspace, ep->workspace_bytes, st);
+        if (rc != KALLE_ERR_UNSUPPORTED) {
+            g_last_plan = 4 | (1 << 8);
+            return rc;
+        }
+    }
     if (force_mode() != 1) {
         const int rc = kalle_gemm_v2_launch(p, a_kmajor != 0, b_kmajor != 0, f32, st);
         if (rc != KALLE_ERR_UNSUPPORTED) {

@@ -30,6 +30,9 @@ struct GemmParams {
     int glu_mode, glu_inner;
     void* glu_aux;
     float* glu_dbias;
+    // few-rows split-K (gemm2 only): K slice s stores its partial tile to C + s * slab_stride (plain stores, summed in a fixed
+    // order by the finishing pass: deterministic, and plain stores run ~4x the rate of float atomics); 0: off
+    int64_t slab_stride;
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a

@@ -88,6 +88,10 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     ep.glu_mode, ep.glu_inner = glu_mode, glu_inner
     ep.glu_aux = glu_aux.data_ptr() if glu_aux is not None else None
     ep.glu_dbias = glu_dbias.data_ptr() if glu_dbias is not None else None
+    if M <= FEW_ROWS_MAX and not a_kmajor and FEW_ROWS:
+        # few output rows (sampling, small training batches): lend the kernel an fp32 [M][N] scratch so it may split K
+        ws = _workspace(a.device, 4 * M * N * 8)
+        ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws.numel()
     if bias is not None:
         assert bias.dtype == torch.float32
     if gate is not None:
@@ -107,12 +111,29 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     if prof is not None:
         e1.record()
         plan = lib.kalle_gemm_last_plan()
-        kname = {1: "gemm_bf16_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel"}.get(plan & 255, "gemm")
+        kname = {1: "gemm_bf16_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel", 4: "gemm2_splitk+finish"}.get(plan & 255, "gemm")
         variant = "%s<%d,%d,%d%s>" % (kname, int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32),
                                       ",glu%d" % glu_mode if glu_mode else "")      # (the fused-SwiGLU kernels are their own rows)
         abytes = 2.0 * (M * K + N * K) + M * N * out.element_size() + (4.0 * M * N if residual is not None else 0.0)
         prof.append((variant, 2.0 * M * N * K, e0, e1, abytes, (M, N, K)))
     return out
+
+
+FEW_ROWS = os.environ.get("KALLE_GEMM_FEW_ROWS", "1") != "0"
+FEW_ROWS_MAX = int(os.environ.get("KALLE_GEMM_FEW_ROWS_MAX", "512"))   # (larger M: the slab traffic eats the gain - DESIGN.md)
+_WS = {}
+_WS_KEEP = []
+
+
+def _workspace(device, nbytes):
+    """per (device, stream) scratch for kalle_gemm_bf16's few-rows path, grown on demand (never shrinks)"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        if t is not None:
+            _WS_KEEP.append(t)          # a captured HIP graph may still point at the old scratch: never hand it back
+        t = _WS[key] = torch.empty(max(min(nbytes, 1 << 30), 64 << 20), device=device, dtype=torch.uint8)
+    return t
 
 
 # bench.py sets this to a list to collect (kernel variant, algorithmic flops, start event, end event) per GEMM launch:

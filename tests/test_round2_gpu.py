@@ -776,3 +776,67 @@ def test_training_step_with_enable_grad_pretransform(dev, monkeypatch):
     tr = engine.DataParallelTrainer(model, lr=1e-4)
     assert "_vae" in tr.flat.bucket_keys
     assert any(k.startswith("pretransform.") for k in tr.flat.names)
+
+
+# ------------------------------------------------------------------------------------------------ few-rows GEMM path
+@pytest.mark.parametrize("M,N,K", [(252, 1536, 1536), (252, 4608, 1536), (126, 1536, 6144), (2016, 1536, 12288), (504, 768, 200)])
+@pytest.mark.parametrize("b_km", [False, True])
+def test_gemm_few_rows_splitk_path(dev, M, N, K, b_km):
+    """M <= 4096 rows (sampling at generation batch sizes, B = 16 training): K is cut into slices that write fp32 slabs into the
+    caller's scratch, a finishing pass sums them in order and applies the epilogue.  Same numbers as the ordinary path (fp32
+    accumulation of the same bf16 products), every epilogue option, and bitwise identical from run to run."""
+    from kalle_audio_amd import ops, _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+    b = (torch.randn(K, N, generator=g) if b_km else torch.randn(N, K, generator=g)).to(dev).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    Bm = b.double() if b_km else b.double().T
+    ref = (a.double() @ Bm)
+    lib = _lib.load()
+
+    def run(**kw):
+        out = ops.gemm(a, b, b_kmajor=b_km, **kw)
+        return out, lib.kalle_gemm_last_plan() & 255
+
+    y, plan = run(out_dtype=torch.float32)
+    assert plan == 4, plan                                         # the split-K + finish path really ran
+    assert rel(y, ref.float()) < 2e-5
+    y2, _ = run(out_dtype=torch.float32)
+    assert torch.equal(y, y2)                                      # slabs summed in slice order: reproducible bit for bit
+    y, _ = run(out_dtype=torch.float32, bias=bias, residual=res)
+    assert rel(y, (ref + bias.double() + res.double()).float()) < 2e-5
+    y, _ = run(out_dtype=torch.bfloat16, bias=bias)
+    assert rel(y, (ref + bias.double()).float()) < 4e-3
+    acc = res.clone()
+    y, _ = run(out=acc, accumulate=True)
+    assert rel(acc, (ref + res.double()).float()) < 2e-5
+    ops.FEW_ROWS = False
+    try:
+        y0, plan0 = run(out_dtype=torch.float32, bias=bias, residual=res)
+    finally:
+        ops.FEW_ROWS = True
+    assert plan0 != 4
+    y, _ = run(out_dtype=torch.float32, bias=bias, residual=res)
+    assert rel(y, y0) < 1e-5
+
+
+def test_gemm_few_rows_fused_swiglu_forward(dev):
+    """the FeedForward's first GEMM at sampling sizes: h = x W^T + b and act = h_x * silu(h_gate) out of the finishing pass,
+    against the separate GEMM + kalle_swiglu_fwd"""
+    from kalle_audio_amd import ops
+    M, D, inner = 252, 1536, 6144
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, D, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(2 * inner, D, generator=g) * 0.03).to(dev).to(torch.bfloat16)
+    bias = torch.randn(2 * inner, generator=g).to(dev)
+    hf = torch.empty(M, 2 * inner, device=dev, dtype=torch.bfloat16)
+    act = torch.empty(M, inner, device=dev, dtype=torch.bfloat16)
+    assert ops.gemm(x, w, bias=bias, out=hf, glu_mode=1, glu_inner=inner, glu_aux=act) is not None
+    ops.FEW_ROWS = False
+    try:
+        h0 = ops.gemm(x, w, bias=bias)
+    finally:
+        ops.FEW_ROWS = True
+    a0 = ops.swiglu_fwd(h0)
+    assert rel(hf, h0) < 4e-3 and rel(act, a0) < 6e-3
