@@ -973,7 +973,9 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
         return KALLE_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ws) & 15) return KALLE_ERR_UNSUPPORTED;
     const int nk = (pin.K + BK2 - 1) / BK2;
-    const int tiles = ((pin.M + 255) / 256) * ((pin.N + 127) / 128);
+    // (256 x 64 tiles with 4 waves - twice the column tiles, half the K slices - measured 5 % slower on the sampling step)
+    constexpr int bn = 128;
+    const int tiles = ((pin.M + 255) / 256) * ((pin.N + bn - 1) / bn);
     if (tiles >= 192) return KALLE_ERR_UNSUPPORTED;                 // enough output tiles on their own
     int splits = (320 + tiles - 1) / tiles;                          // ~1.25 workgroups per CU
     if (splits > nk / 2) splits = nk / 2;                            // at least two K-tiles per slice
@@ -986,7 +988,7 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     q.M = pin.M; q.N = pin.N; q.K = pin.K;
     q.alpha = 1.f;
     q.rows_per_batch = 1;
-    q.tiles_m = (pin.M + 255) / 256; q.tiles_n = (pin.N + 127) / 128; q.tile_n = 128;
+    q.tiles_m = (pin.M + 255) / 256; q.tiles_n = (pin.N + bn - 1) / bn; q.tile_n = bn;
     q.group_m = q.tiles_m < 4 ? q.tiles_m : 4;
     q.atomic = 0;
     q.mix_na = -1;

@@ -2,6 +2,7 @@
 --steps 2 --warmup 1 --no-cpu-baseline`.   python tools/pmc_mfma_summary.py DIR"""
 import collections, csv, glob, sys
 d = sys.argv[1]
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt, dur = collections.Counter(), collections.defaultdict(float)
 for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])):
@@ -11,7 +12,7 @@ for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recurs
         cnt[name] += 1
         dur[name] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(dur.values())
-L = ["# MFMA-pipe utilisation on the DiT path (rocprofv3 PMC, round 1)\n",
+L = [f"# MFMA-pipe utilisation on the DiT path (rocprofv3 PMC, {TAG})\n",
      "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
      "(its own pass, no other counters or traces).  SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over the 1024",
      "SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so clock = GUI_ACTIVE / 8 / kernel time and",
@@ -28,5 +29,5 @@ gb = sum(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"] for _, k in rows if "gemm" in k)
 ga = sum(agg[k]["GRBM_GUI_ACTIVE"] / 8.0 for _, k in rows if "gemm" in k)
 L.append(f"\nAll GEMM kernels together: MFMA pipe {100*gb/(ga*1024):.1f} % busy; all kernels of the step: "
          f"{100*sum(v['SQ_VALU_MFMA_BUSY_CYCLES'] for v in agg.values())/(sum(v['GRBM_GUI_ACTIVE'] for v in agg.values())/8*1024):.1f} %.")
-open("profiles/r01_pmc_mfma_util.md", "w").write("\n".join(L) + "\n")
+open(f"profiles/{TAG}_pmc_mfma_util.md", "w").write("\n".join(L) + "\n")
 print("\n".join(L))
