@@ -1021,7 +1021,8 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
     // weights small enough to stay in one XCD's L2: run the channel tiles of a position tile back to back (x re-read hits L2)
     p.co_fast = (int64_t)Cin * ksize * p.CoutP * 4 <= (2 << 20);
     const bool v2_stride = stride == 1 || (dilation == 1 && (stride == 2 || stride == 4 || stride == 8) && ksize <= 32);
-    if (v2_stride && p.act != 4 && xf == yf && !getenv("KALLE_CONV_V1")) {
+    static const bool v1_env = getenv("KALLE_CONV_V1") != nullptr;       // experiment switch, read once per process
+    if (v2_stride && p.act != 4 && xf == yf && !v1_env) {
 #define KALLE_CONV_V2N(COW, LPT, WCO, CI, SPAN, NW)                                                                    \
     do {                                                                                                                \
         p.ntile = (Lout + 64 * LPT * (NW / WCO) - 1) / (64 * LPT * (NW / WCO));                                        \
@@ -1191,7 +1192,8 @@ extern "C" int kalle_conv_transpose1d_fwd(const void* x, int x_dtype, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool xf = x_dtype == KALLE_F32, yf = y_dtype == KALLE_F32;
     const int mmax = (ksize + stride - 1) / stride;
-    if (xf == yf && mmax <= 64 && !getenv("KALLE_CONV_V1")) {
+    static const bool v1_env = getenv("KALLE_CONV_V1") != nullptr;
+    if (xf == yf && mmax <= 64 && !v1_env) {
         const int nq = (Lout - 1 + padding) / stride + 1;      // input positions that reach an output
 #define KALLE_CONVT_V2(COW, LPT, WCO)                                                                                  \
     do {                                                                                                                \

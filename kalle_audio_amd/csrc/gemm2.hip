@@ -806,7 +806,9 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     // slices are dispatched first: the last round of workgroups then consists of short slices instead of leaving most CUs idle
     // (288 tiles x 3 slices = 3.4 rounds -> 4 with uniform splitting).  The plan comes from replaying the dispatch on 256 CUs
     // (time of a slice = 10 us + 1.6 us per K-tile, atomics at 2 TB/s - fitted to tools/wgrad_sweep.py) and is cached per shape.
-    if (can_split && best_bn == 256 && !tile_env && !getenv("KALLE_GEMM_NOMIX")) {
+    static const bool nomix_env = getenv("KALLE_GEMM_NOMIX") != nullptr, debug_env = getenv("KALLE_GEMM_DEBUG") != nullptr;
+    static const char* const mix_env = getenv("KALLE_GEMM_MIX");          // experiment switches: read once per process
+    if (can_split && best_bn == 256 && !tile_env && !nomix_env) {
         struct Plan { int M, N, kb, sa, na; };          // kb: K-tiles / 16 (a plan is valid for any K; nearby K share it)
         static thread_local Plan cache[32];
         static thread_local int ncache = 0, victim = 0;
@@ -865,10 +867,10 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
             na_sel = hit->na;
         }
         if (na_sel > 0 && nk / (sa_sel + 1) < 8) na_sel = -1;    // (a cached plan of a longer K)
-        if (getenv("KALLE_GEMM_DEBUG")) fprintf(stderr, "[kalle gemm] %d x %d x %d: mixed split sa=%d na=%d (hit=%d)\n", p.M, p.N, p.K, sa_sel, na_sel, hit != nullptr);
+        if (debug_env) fprintf(stderr, "[kalle gemm] %d x %d x %d: mixed split sa=%d na=%d (hit=%d)\n", p.M, p.N, p.K, sa_sel, na_sel, hit != nullptr);
         if (na_sel > 0) { p.mix_na = na_sel; p.mix_sa = sa_sel; best_s = sa_sel + 1; }
     }
-    if (const char* e = getenv("KALLE_GEMM_MIX")) {      // "sa,na": experiment override
+    if (const char* e = mix_env) {      // "sa,na": experiment override
         int sa = 0, na = 0;
         if (can_split && sscanf(e, "%d,%d", &sa, &na) == 2 && sa >= 1 && best_bn == 256 && nk / (sa + 1) >= 8) {
             const int ntiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -1056,7 +1058,8 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
             g_last_plan = (p.tile_n == 256 ? 3 : 2) | (p.splits << 8);
             return rc;
         }
-        if (force_mode() == 2 && getenv("KALLE_GEMM_STRICT")) return rc;
+        static const bool strict_env = getenv("KALLE_GEMM_STRICT") != nullptr;
+        if (force_mode() == 2 && strict_env) return rc;
     }
     if (p.glu_mode) return KALLE_ERR_UNSUPPORTED;   // fused SwiGLU exists only in the 256x256 kernel: caller un-fuses
     p.tiles_n = (N + 127) / 128;
