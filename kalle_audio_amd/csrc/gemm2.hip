@@ -980,7 +980,10 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     const int tiles = ((pin.M + 255) / 256) * ((pin.N + bn - 1) / bn);
     if (tiles >= 192) return KALLE_ERR_UNSUPPORTED;                 // enough output tiles on their own
     int splits = (320 + tiles - 1) / tiles;                          // ~1.25 workgroups per CU
-    if (splits > nk / 2) splits = nk / 2;                            // at least two K-tiles per slice
+    // at least two K-tiles per slice; with more than a couple of tile rows (training at small batch) a slice must be long
+    // enough (16 K-tiles) to pay for its slab: M x N x 4 bytes written and read back per slice
+    const int min_per = pin.M > 512 ? 16 : 2;
+    if (splits > nk / min_per) splits = nk / min_per;
     const int64_t slab = (int64_t)pin.M * pin.N;
     if (splits > ws_bytes / (4 * slab)) splits = (int)(ws_bytes / (4 * slab));   // one fp32 [M][N] slab per slice
     if (splits < 2) return KALLE_ERR_UNSUPPORTED;

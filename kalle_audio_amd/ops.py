@@ -120,7 +120,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
 
 
 FEW_ROWS = os.environ.get("KALLE_GEMM_FEW_ROWS", "1") != "0"
-FEW_ROWS_MAX = int(os.environ.get("KALLE_GEMM_FEW_ROWS_MAX", "512"))   # (larger M: the slab traffic eats the gain - DESIGN.md)
+FEW_ROWS_MAX = int(os.environ.get("KALLE_GEMM_FEW_ROWS_MAX", "4096"))  # (the dispatcher decides per shape)
 _WS = {}
 _WS_KEEP = []
 

@@ -840,3 +840,35 @@ def test_gemm_few_rows_fused_swiglu_forward(dev):
         ops.FEW_ROWS = True
     a0 = ops.swiglu_fwd(h0)
     assert rel(hf, h0) < 4e-3 and rel(act, a0) < 6e-3
+
+
+def test_encode_latents_example_writes_reference_latent_files(dev, tmp_path):
+    """examples/encode_latents_hip.py (the GPU replacement of the reference's CPU-worker encode, twj_dataset.py:225-239):
+    writes mean || scale [2 * latent_dim, T] .npy files (the format twj_data_offline_sd2.py:279-287 reads) equal to a direct
+    pretransform.encode of the same normalised clip"""
+    import subprocess
+    import kalle_audio_amd
+    kalle_audio_amd.install()
+    from stable_audio_tools.models.factory import create_model_from_config
+    cfg = gu.oobleck_cfg(True)
+    (tmp_path / "model_config.json").write_text(json.dumps(cfg))
+    ae = create_model_from_config(cfg)
+    load_seeded(ae, 23, dev)
+    torch.save({"state_dict": ae.state_dict()}, tmp_path / "vae.ckpt")
+    wav = gu.make_input("clip", (2, 9013), 67, 0.3)                 # not a multiple of the downsampling ratio (40)
+    np.save(tmp_path / "clip0.npy", wav)
+    (tmp_path / "clips.txt").write_text(str(tmp_path / "clip0.npy") + "\n")
+    script = os.path.join(HERE, "..", "examples", "encode_latents_hip.py")
+    r = subprocess.run([sys.executable, script, "--model-config", str(tmp_path / "model_config.json"), "--ckpt",
+                        str(tmp_path / "vae.ckpt"), "--list", str(tmp_path / "clips.txt"), "--out", str(tmp_path / "lat")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / "lat" / "clip0.npy")
+    mono = wav.mean(0)
+    mono = mono / np.abs(mono).max() * 0.95
+    mono = np.pad(mono, (0, (-len(mono)) % 40))
+    x = torch.from_numpy(mono).to(dev).view(1, 1, -1).repeat(1, 2, 1)
+    with torch.no_grad():
+        ref = ae.encode(x)[0]
+    assert z.shape == (8, len(mono) // 40) and z.dtype == np.float32
+    assert rel(torch.from_numpy(z), ref) < 1e-5
