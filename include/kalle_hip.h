@@ -197,7 +197,9 @@ typedef struct kalle_wgrad_problem {
     int64_t lddw;
     int32_t N, K, tokens;
 } kalle_wgrad_problem;
-int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, void* stream);
+/* overwrite != 0: dw_i = dy_i^T x_i instead (no clear needed: tiles that run whole store their result, the regions of the
+ * tiles that are cut into token slices are cleared by a small launch first) */
+int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, int overwrite, void* stream);
 
 /* Chunked VAE encode / decode (AudioAutoencoder.encode_audio / decode_audio, autoencoders.py:429-560) as a batched pipeline:
  * every chunk rides on the batch axis of ONE encoder / decoder pass; this call is the gather in front of it and the paste

@@ -534,7 +534,7 @@ extern "C" void kalle_set_last_error(const char* what) {
     snprintf(g_last_error, sizeof(g_last_error), "%s", what ? what : "");
 }
 extern "C" const char* kalle_last_error(void) { return g_last_error; }
-extern "C" int kalle_abi_version(void) { return 1; }
+extern "C" int kalle_abi_version(void) { return 2; }   // 2: kalle_gemm_epilogue.workspace, kalle_gemm_wgrad_group, conv backward
 extern "C" const char* kalle_target_arch(void) { return "gfx950"; }
 
 extern "C" int kalle_segment_copy(const void* src, void* dst, int dtype, int nseg, const int64_t* src_off,

@@ -669,8 +669,29 @@ struct GroupProblem {
 };
 struct GroupParams {
     int nprob, r2_base;
+    int overwrite;         // whole tiles STORE their result (dW = ...) instead of adding to it; the sliced tiles were zeroed first
     GroupProblem pr[KALLE_MAX_GROUP];
 };
+
+// overwrite mode: the 256 x 256 regions of the tiles that are cut into K slices (atomic adds) are cleared by this launch first
+__global__ __launch_bounds__(256) void gemm3_group_zero_kernel(GroupParams gp) {
+    int pi = 0, base = 0;
+    const int bid = blockIdx.x >> 2, band = blockIdx.x & 3;   // four workgroups (64-row bands) per sliced tile, problems in order
+    for (;;) {
+        const int nb = gp.pr[pi].tiles_m * gp.pr[pi].tiles_n - gp.pr[pi].unsplit;
+        if (bid < base + nb || pi + 1 >= gp.nprob) break;
+        base += nb;
+        ++pi;
+    }
+    const GroupProblem& q = gp.pr[pi];
+    int tm, tn;
+    gemm_tile_coords_plain(q.unsplit + bid - base, q.tiles_m, q.tiles_n, q.group_m, tm, tn);
+    const int r0 = tm * 256 + band * 64, c0 = tn * 256;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = r0 + i / 64, c = c0 + (i & 63) * 4;
+        if (r < q.M && c < q.N) *reinterpret_cast<f32x4*>(q.C + (int64_t)r * q.ldc + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
 
 __global__ __launch_bounds__(512, 2) void gemm3_wgrad_group_kernel(GroupParams gp) {
     // blocks b, b + 8, ... share an XCD (and its L2): give every XCD a contiguous run of each region's work order, so that
@@ -695,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_group_kernel(GroupParams g
     p.M = q.M; p.N = q.N; p.K = q.K;
     p.alpha = 1.f;
     p.rows_per_batch = 1;
-    p.accumulate = 1;
+    p.accumulate = gp.overwrite ? 0 : 1;
     p.atomic = whole ? 0 : 1;
     const int ntiles = q.tiles_m * q.tiles_n, nk_all = (q.K + BK2 - 1) / BK2;
     int tm, tn;
@@ -1110,10 +1131,11 @@ double replay_group(const GroupProblem* pr, int n, int unsplit_total, int splits
 }
 }  // namespace
 
-extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, void* stream) {
+extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int nprob, int overwrite, void* stream) {
     if (!problems || nprob <= 0 || nprob > KALLE_MAX_GROUP) return KALLE_ERR_ARG;
     GroupParams gp{};
     gp.nprob = nprob;
+    gp.overwrite = overwrite ? 1 : 0;
     int ntot = 0, min_nk = 1 << 30;
     uint64_t key = 1469598103934665603ull;
     for (int i = 0; i < nprob; ++i) {
@@ -1180,6 +1202,11 @@ extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int n
     static const bool dbg = getenv("KALLE_GEMM_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[kalle wgrad group] %d problems, %d tiles: %d whole + %d x %d slices = %d workgroups\n", nprob, ntot,
                      b1, ntot - b1, plan.splits, b2);
+    if (gp.overwrite && ntot - b1 > 0 && plan.splits >= 1) {
+        // (N % 4 == 0 is implied by N % 8 == 0: the clears are 16-byte stores)
+        KALLE_LAUNCH(gemm3_group_zero_kernel, dim3(4 * (ntot - b1)), dim3(256), 0, static_cast<hipStream_t>(stream), gp);
+        if (kalle_check_launch() != KALLE_OK) return KALLE_ERR_LAUNCH;
+    }
     constexpr int lds = 2 * (256 + 256) * 128;
     static std::atomic<uint64_t> lds_ok{0};
     kalle_allow_lds(reinterpret_cast<const void*>(gemm3_wgrad_group_kernel), lds, lds_ok);

@@ -55,6 +55,7 @@ class GradOut:
         self.prefix = prefix
         self.grads = {}
         self.deferred = None            # list of (name, dy, x) while a block's weight gradients are being collected
+        self.wgrad_overwrite = False    # trainer, first micro-batch: weight-gradient sinks are NOT pre-cleared - write, don't add
 
     def _sink(self, name):
         return self.sinks.get(self.prefix + name)
@@ -70,19 +71,18 @@ class GradOut:
         if not items:
             return
         probs = []
+        over = self.wgrad_overwrite or not self.accumulate or not self.sinks
         for name, dy, x in items:
             s = self._sink(name)
             if s is not None:
-                if not self.accumulate:
-                    s.zero_()
                 out = s
                 self.grads[name] = None
             else:
-                out = self.grads[name] = torch.zeros((dy.shape[1], x.shape[1]), device=dy.device, dtype=F32)
+                out = self.grads[name] = torch.empty((dy.shape[1], x.shape[1]), device=dy.device, dtype=F32)
             probs.append((dy, x, out))
-        if not ops.gemm_wgrad_group(probs):        # shapes outside the grouped kernel: one GEMM each, accumulating
+        if not ops.gemm_wgrad_group(probs, overwrite=over):    # shapes outside the grouped kernel: one GEMM each
             for dy, x, out in probs:
-                ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=True)
+                ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=out, accumulate=not over)
 
     def wgrad(self, name, dy, x):
         """dW[N,K] = dy[M,N]^T @ x[M,K]"""
@@ -91,7 +91,7 @@ class GradOut:
             return
         s = self._sink(name)
         if s is not None:
-            ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=self.accumulate)
+            ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=self.accumulate and not self.wgrad_overwrite)
             self.grads[name] = None
         else:
             self.grads[name] = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)

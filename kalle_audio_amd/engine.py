@@ -126,14 +126,19 @@ class FlatBuckets:
         self.bucket_keys = order
         self.slices = {}          # name -> (start, numel)
         self.bucket_range = {}    # key -> (start, end)
-        off = 0
-        for k in order:
+        self.small_range = {}     # key -> (start, end) of the bucket's vectors (norm scales, biases): they lead the bucket, so one
+        off = 0                   # clear per bucket serves every sink the kernels ADD into; the matrices behind them are written
+        for k in order:           # whole by the grouped weight-gradient launch of the first micro-batch
             start = off
-            for n, p in named_params:
-                if bucket_of(n) != k:
-                    continue
-                self.slices[n] = (off, p.numel())
-                off += (p.numel() + align - 1) // align * align
+            members = [(n, p) for n, p in named_params if bucket_of(n) == k]
+            for want_small in (True, False):
+                for n, p in members:
+                    if (p.dim() < 2) != want_small:
+                        continue
+                    self.slices[n] = (off, p.numel())
+                    off += (p.numel() + align - 1) // align * align
+                if want_small:
+                    self.small_range[k] = (start, off)
             self.bucket_range[k] = (start, off)
         self.total = off
         self.param = torch.zeros(off, device=device, dtype=torch.float32)
@@ -271,15 +276,24 @@ class DataParallelTrainer:
         # that writes its output whole would have to read the cleared buffer back instead (B = 16: -5 %), so small
         # micro-batches keep the overwrite-on-first-micro-batch rule.
         rows = max((getattr(blk, "_kalle_last_rows", 0) for _, blk in self.blocks), default=0)
-        # (the grouped weight-gradient launch of a block always accumulates into the sinks: one clear serves it too)
         from . import dit_ops
-        clear_once = rows >= 8192 or (dit_ops.GROUP_WGRAD and rows > 0 and rows % 8 == 0)
+        # With the grouped weight-gradient launch (every block's matrices in one kernel) the first micro-batch WRITES the matrix
+        # gradients - no clear of the 4.2 GB they occupy and no read-add-store - and only the vectors at the head of every bucket
+        # (norm scales, biases: sinks the kernels add into atomically) are cleared, one small memset per bucket.
+        grouped = dit_ops.GROUP_WGRAD and rows > 0 and rows % 8 == 0
+        clear_once = rows >= 8192 and not grouped
         for _, blk in self.blocks:
-            blk._kalle_grad_accumulate = True if clear_once else not first
+            blk._kalle_grad_accumulate = True if (clear_once or grouped) else not first
+            blk._kalle_wgrad_overwrite = grouped and first
         if first:
             if clear_once:
                 self.flat.grad.zero_()
             else:
+                if grouped:
+                    for _, blk in self.blocks:
+                        a, b = self.flat.small_range[blk._kalle_bucket_key]
+                        if b > a:
+                            self.flat.grad[a:b].zero_()
                 for key in ("_rest", "_vae"):
                     if key in self.flat.bucket_range:
                         self.flat.bucket_grad(key).zero_()     # autograd accumulates (+=) into these views

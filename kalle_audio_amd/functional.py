@@ -315,6 +315,7 @@ class TransformerBlockFn(torch.autograd.Function):
         gf = _to_f32(g.contiguous()).view(B * N, Dm)
         sinks = getattr(blk, "_kalle_grad_sinks", None)
         go = D.GradOut(sinks, getattr(blk, "_kalle_grad_accumulate", False)) if sinks else D.GradOut()
+        go.wgrad_overwrite = bool(sinks) and getattr(blk, "_kalle_wgrad_overwrite", False)
         # bf16 copy of the incoming gradient, if the block above (layer_ix + 1) left one for exactly this tensor
         sh = _GRAD_SHADOW.pop(gf.data_ptr(), None)
         g_bf16 = None

@@ -49,6 +49,7 @@ class LlamaLayerFn(torch.autograd.Function):
         gf = g.contiguous().view(B * L, Dm)
         sinks = getattr(layer, "_kalle_grad_sinks", None)
         go = GradOut(sinks, getattr(layer, "_kalle_grad_accumulate", False)) if sinks else GradOut()
+        go.wgrad_overwrite = bool(sinks) and getattr(layer, "_kalle_wgrad_overwrite", False)
         sh = Fn._GRAD_SHADOW.pop(gf.data_ptr(), None)
         g_bf16 = sh[1] if sh is not None and sh[0] == ("llama", layer.layer_idx + 1) and sh[1].shape == gf.shape else None
         if len(Fn._GRAD_SHADOW) > 8:

@@ -543,9 +543,9 @@ def segment_copy(src, dst, src_off, dst_off, lens, nbatch, rows, *, src_strides,
 MAX_GROUP = 8
 
 
-def gemm_wgrad_group(problems):
-    """problems: list of (dy bf16 [tokens, N], x bf16 [tokens, K], dw fp32 [N, K]); dw += dy^T x for all of them in one launch
-    per 8.  Returns False (nothing launched) when the shapes are outside the grouped kernel's domain."""
+def gemm_wgrad_group(problems, overwrite=False):
+    """problems: list of (dy bf16 [tokens, N], x bf16 [tokens, K], dw fp32 [N, K]); dw += dy^T x (overwrite: dw = dy^T x) for
+    all of them in one launch per 8.  Returns False (nothing launched) when the shapes are outside the grouped kernel's domain."""
     lib = _lib.load()
     for dy, x, dw in problems:
         if dy.shape[0] % 8 or dy.shape[0] != x.shape[0] or dy.shape[1] % 8 or x.shape[1] % 8:
@@ -566,7 +566,7 @@ def gemm_wgrad_group(problems):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = lib.kalle_gemm_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(grp), _stream())
+        rc = lib.kalle_gemm_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), len(grp), int(bool(overwrite)), _stream())
         if rc == -3 and g == 0:
             return False
         check(rc, "kalle_gemm_wgrad_group")

@@ -23,10 +23,29 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(lib, name), name
     lib.kalle_abi_version.restype = ctypes.c_int
-    assert lib.kalle_abi_version() == 1
+    assert lib.kalle_abi_version() == 2
     lib.kalle_target_arch.restype = ctypes.c_char_p
     assert lib.kalle_target_arch() == b"gfx950"
-    assert ctypes.sizeof(_lib.GemmEpilogue) == 104  # matches the C struct layout (checked against hipcc's sizeof)
+    # the ctypes mirrors match the C structs of the header: sizes and every field offset, as the C compiler lays them out
+    import subprocess
+    import tempfile
+    pairs = (("kalle_gemm_epilogue", _lib.GemmEpilogue), ("kalle_act", _lib.Act), ("kalle_conv_epilogue", _lib.ConvEpilogue),
+             ("kalle_llama_layer", _lib.LlamaLayer), ("kalle_wgrad_problem", _lib.WgradProblem))
+    lines = []
+    for cname, cls in pairs:
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "kalle_hip.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+        out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split("\n")
+    for (cname, cls), line in zip(pairs, out):
+        got = line.split()
+        want = [cname, str(ctypes.sizeof(cls))] + [str(getattr(cls, f).offset) for f, _ in cls._fields_]
+        assert got == want, (got, want)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
