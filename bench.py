@@ -136,6 +136,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (the product path has no CPU fallback)")
+    local = local % torch.cuda.device_count()       # (one rank per GPU; a gloo rehearsal may put several ranks on one device)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

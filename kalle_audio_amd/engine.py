@@ -73,9 +73,12 @@ def init_distributed(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or os.environ.get("KALLE_FORCE_COMM")) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # (KALLE_DIST_BACKEND=gloo: rehearse the multi-rank control flow on one GPU, where RCCL refuses two ranks per device)
+            backend = os.environ.get("KALLE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
