@@ -429,6 +429,10 @@ int kalle_act_bwd(const float* x, const float* g, float* dx, const kalle_act* ac
                   int L, void* stream);
 /* g = dy * (1 - y^2): the decoder's final tanh (autoencoders.py:185) */
 int kalle_tanh_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream);
+/* nn.Upsample(scale_factor=scale, mode="nearest") along the last axis (DecoderBlock use_nearest_upsample, autoencoders.py:87-89):
+ * backward == 0: x [rows][L] -> y [rows][L*scale], y[r][l] = x[r][l / scale];
+ * backward != 0: x = dy [rows][L*scale] -> y = dx [rows][L], dx[r][m] = sum_{j<scale} dy[r][m*scale + j].  fp32, scale 1..64 */
+int kalle_upsample_nearest(const float* x, float* y, int64_t rows, int L, int scale, int backward, void* stream);
 /* out[c] += sum_{b, l} x[b][c][l]  (bias gradient; out zeroed or accumulated by the caller) */
 int kalle_channel_sum(const float* x, float* out, int B, int C, int L, void* stream);
 /* torch weight_norm (dim 0) backward: w = g v / ||v|| per slice of dim 0 (n = elements per slice):

@@ -55,6 +55,30 @@ def tanh_bwd(dy, y):
     return g
 
 
+def upsample_nearest(x, scale, backward=False):
+    """nn.Upsample(scale_factor=scale, mode='nearest') on [B, C, L] fp32, or (backward) its adjoint on [B, C, L*scale]"""
+    lib = _lib.load()
+    x = x.contiguous().float()
+    B, C, L = x.shape
+    if backward:
+        assert L % scale == 0
+        L //= scale
+    y = torch.empty((B, C, L if backward else L * scale), device=x.device, dtype=F32)
+    check(lib.kalle_upsample_nearest(_p(x), _p(y), B * C, L, int(scale), int(backward), _stream()), "kalle_upsample_nearest")
+    return y
+
+
+class UpsampleNearestFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return upsample_nearest(x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return upsample_nearest(dy, ctx.scale, backward=True), None
+
+
 def channel_sum(x):
     lib = _lib.load()
     B, C, L = x.shape
@@ -94,12 +118,13 @@ class ActConvFn(torch.autograd.Function):
         x = x.contiguous().float()
         kind, K, stride, pad, dil = cfg["kind"], cfg["K"], cfg["stride"], cfg["padding"], cfg["dilation"]
         act, ls, tanh = cfg["act"], cfg["logscale"], cfg["tanh"]
+        pr = cfg.get("pad_right")       # 'same' with an even kernel: one more zero on the right than on the left
         b32 = bias.detach().float() if bias is not None else None
         a32 = alpha.detach().float() if alpha is not None else None
         be32 = beta.detach().float() if beta is not None else None
         if kind == "conv":
             y = conv_ops.conv1d(x, _fold(v, g, 0), b32, Cout=v.shape[0], K=K, stride=stride, padding=pad, dilation=dil, act=act,
-                                alpha=a32, beta=be32, logscale=ls,
+                                alpha=a32, beta=be32, logscale=ls, pad_right=pr,
                                 residual=residual.contiguous().float() if residual is not None else None, post=int(tanh))
         else:
             assert residual is None and not tanh
@@ -127,8 +152,9 @@ class ActConvFn(torch.autograd.Function):
         dxa = None
         if ctx.needs_input_grad[0] or (act == 1 and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5])):
             if kind == "conv" and stride == 1:
+                pr = cfg.get("pad_right")
                 dxa = conv_ops.conv1d(gy, _fold(v, g, 1 | 2), None, Cout=Cx, K=K, stride=1, padding=(K - 1) * dil - pad,
-                                      dilation=dil)
+                                      dilation=dil, pad_right=None if pr is None else (K - 1) * dil - pr)
             elif kind == "conv":
                 # transposed conv over gy; the symmetric right trim of `pad` outputs is given back as far as x reaches
                 nat = (gy.shape[2] - 1) * stride - 2 * pad + K
@@ -178,5 +204,6 @@ def act_conv(x, conv, act_module=None, residual=None, tanh=False):
     elif act_module is not None and not isinstance(act_module, nn.Identity):
         raise NotImplementedError(f"activation {type(act_module).__name__}")
     cfg = dict(kind="convT" if conv.transposed else "conv", K=conv.kernel_size, stride=conv.stride, padding=conv.padding,
-               dilation=getattr(conv, "dilation", 1), act=code, logscale=ls, tanh=bool(tanh))
+               dilation=getattr(conv, "dilation", 1), act=code, logscale=ls, tanh=bool(tanh),
+               pad_right=getattr(conv, "pad_right", None))
     return ActConvFn.apply(x, conv.weight_v, conv.weight_g, conv.bias, alpha, beta, residual, cfg)

@@ -168,6 +168,27 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
         g[i] = dy[i] * (1.f - y[i] * y[i]);
 }
 
+// nn.Upsample(scale_factor=s, mode="nearest") along L (autoencoders.py:88): y[r][l] = x[r][l / s]; adjoint: dx[r][m] = sum_j dy[r][m*s+j]
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_out,
+                                                               int Lout, int s) {
+    const int Lin = Lout / s;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Lout;
+        const int l = (int)(i - r * Lout);
+        y[i] = x[r * Lin + l / s];
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t n_in,
+                                                                   int s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* g = dy + i * s;        // rows are contiguous, so element i of dx owns dy[i*s .. i*s+s)
+        float acc = 0.f;
+        for (int j = 0; j < s; ++j) acc += g[j];
+        dx[i] = acc;
+    }
+}
+
 // out[c] += sum over (b, l) of x[b, c, l]  (bias gradient)
 __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int L,
                                                        int seg) {
@@ -256,6 +277,20 @@ extern "C" int kalle_act_bwd(const float* x, const float* g, float* dx, const ka
 extern "C" int kalle_tanh_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream) {
     if (!dy || !y || !g || n <= 0) return KALLE_ERR_ARG;
     KALLE_LAUNCH(tanh_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, g, n);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_upsample_nearest(const float* x, float* y, int64_t rows, int L, int scale, int backward, void* stream) {
+    if (!x || !y || rows <= 0 || L <= 0 || scale < 1 || scale > 64) return KALLE_ERR_ARG;
+    if (backward) {     // x = dy [rows][L*scale] -> y = dx [rows][L]
+        const int64_t n = rows * L;
+        KALLE_LAUNCH(upsample_nearest_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n,
+                     scale);
+    } else {
+        const int64_t n = rows * L * scale;
+        KALLE_LAUNCH(upsample_nearest_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n,
+                     L * scale, scale);
+    }
     return kalle_check_launch();
 }
 

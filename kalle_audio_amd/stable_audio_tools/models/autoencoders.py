@@ -71,11 +71,14 @@ class WNConv1d(_WNBase):
         super().__init__()
         ref = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride,
                         padding=0 if isinstance(padding, str) else padding, dilation=dilation, bias=bias)
+        self.pad_right = None
         if padding == 'same':
-            # PyTorch 'same': total = dilation*(k-1), left = total//2 ; symmetric only for odd k (asymmetric not built)
-            if (dilation * (kernel_size - 1)) % 2:
-                raise NotImplementedError("padding='same' with an even kernel (use_nearest_upsample path)")
-            padding = dilation * (kernel_size - 1) // 2
+            # PyTorch 'same' (stride 1): total = dilation*(k-1) zeros, left = total // 2, the odd one goes to the right
+            assert stride == 1, "padding='same' is not supported for strided convolutions"
+            total = dilation * (kernel_size - 1)
+            padding = total // 2
+            if total % 2:
+                self.pad_right = total - padding
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
         self.stride, self.padding, self.dilation = stride, padding, dilation
         self.weight_v = nn.Parameter(ref.weight.detach().clone())
@@ -93,7 +96,7 @@ class WNConv1d(_WNBase):
         return conv_ops.conv1d(x, self._packed(), self._bias(), Cout=self.out_channels, K=self.kernel_size,
                                stride=self.stride, padding=self.padding, dilation=self.dilation, act=code, alpha=a,
                                beta=b, logscale=ls, residual=residual, post=post, post_act=_post_act(post_act),
-                               want_raw=want_raw)
+                               want_raw=want_raw, pad_right=self.pad_right)
 
 
 class WNConvTranspose1d(_WNBase):
@@ -196,11 +199,16 @@ class DecoderBlock(nn.Module):
     def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False,
                  use_nearest_upsample=False):
         super().__init__()
-        if use_nearest_upsample:
-            raise NotImplementedError("use_nearest_upsample (nn.Upsample + even-kernel 'same' conv) is not built")
-        upsample_layer = WNConvTranspose1d(in_channels=in_channels, out_channels=out_channels,
-                                           kernel_size=2 * stride + stride % 2, stride=stride,
-                                           padding=math.ceil(stride / 2))
+        self.nearest = stride if use_nearest_upsample else 0
+        if use_nearest_upsample:        # autoencoders.py:87-96; same Sequential nesting, so the state-dict keys match
+            upsample_layer = nn.Sequential(
+                nn.Upsample(scale_factor=stride, mode="nearest"),
+                WNConv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=2 * stride, stride=1, bias=False,
+                         padding='same'))
+        else:
+            upsample_layer = WNConvTranspose1d(in_channels=in_channels, out_channels=out_channels,
+                                               kernel_size=2 * stride + stride % 2, stride=stride,
+                                               padding=math.ceil(stride / 2))
         self.layers = nn.Sequential(
             get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=in_channels),
             upsample_layer,
@@ -212,10 +220,15 @@ class DecoderBlock(nn.Module):
         # every unit's output is needed raw (skip path of the next unit) and activated (its first conv): the producers store
         # both, so no k=7 conv spends VALU time re-activating its input tile once per output-channel tile
         ru = self.layers
+        up = ru[1]
+        if self.nearest:
+            # a pointwise activation commutes with sample repetition: repeat x, then the conv activates while it stages
+            from ... import conv_train
+            x, up = conv_train.UpsampleNearestFn.apply(_prep(x).float(), self.nearest), ru[1][1]
         if _wants_grad(self, x):
             assert not pre_activated
-            return ru[4](ru[3](ru[2](ru[1](x, act=ru[0]))))
-        xa, x = ru[1](x, act=None if pre_activated else ru[0], post_act=ru[2].layers[0], want_raw=True)
+            return ru[4](ru[3](ru[2](up(x, act=ru[0]))))
+        xa, x = up(x, act=None if pre_activated else ru[0], post_act=ru[2].layers[0], want_raw=True)
         xa, x = ru[2](x, post_act=ru[3].layers[0], x_act=xa, dual=True)
         xa, x = ru[3](x, post_act=ru[4].layers[0], x_act=xa, dual=True)
         return ru[4](x, post_act=post_act, x_act=xa)

@@ -342,11 +342,17 @@ def encoder_block(sd, x, stride, use_snake):
     return F.conv1d(x, wn_weight(sd, "layers.4"), sd["layers.4.bias"], stride=stride, padding=math.ceil(stride / 2))
 
 
-def decoder_block(sd, x, stride, use_snake):
-    """autoencoders.py:83-114: act -> transposed conv k=2s+s%2 -> RU(1,3,9). keys layers.{0..4}"""
+def decoder_block(sd, x, stride, use_snake, nearest=False):
+    """autoencoders.py:83-114: act -> transposed conv k=2s+s%2 -> RU(1,3,9). keys layers.{0..4}
+    nearest (use_nearest_upsample, :87-96): act -> repeat each sample `stride` times -> conv k=2s, no bias, padding 'same'
+    (2s-1 zeros in all: s-1 on the left, s on the right), keys layers.1.1.*"""
     x = _act(sd, "layers.0", x, use_snake)
-    x = F.conv_transpose1d(x, wn_weight(sd, "layers.1"), sd["layers.1.bias"], stride=stride,
-                           padding=math.ceil(stride / 2))
+    if nearest:
+        x = torch.repeat_interleave(x, stride, dim=2)
+        x = F.conv1d(F.pad(x, (stride - 1, stride)), wn_weight(sd, "layers.1.1"), None)
+    else:
+        x = F.conv_transpose1d(x, wn_weight(sd, "layers.1"), sd["layers.1.bias"], stride=stride,
+                               padding=math.ceil(stride / 2))
     for i, d in enumerate((1, 3, 9)):
         x = residual_unit(_sub(sd, f"layers.{i + 2}."), x, d, use_snake)
     return x
@@ -362,12 +368,12 @@ def oobleck_encoder(sd, x, strides, use_snake):
     return F.conv1d(x, wn_weight(sd, f"layers.{n + 2}"), sd[f"layers.{n + 2}.bias"], padding=1)
 
 
-def oobleck_decoder(sd, z, strides, use_snake, final_tanh=True):
+def oobleck_decoder(sd, z, strides, use_snake, final_tanh=True, nearest=False):
     """autoencoders.py:150-191 (blocks run over reversed strides; last conv has no bias)"""
     x = F.conv1d(z, wn_weight(sd, "layers.0"), sd["layers.0.bias"], padding=3)
     n = len(strides)
     for j, s in enumerate(reversed(strides)):
-        x = decoder_block(_sub(sd, f"layers.{j + 1}."), x, s, use_snake)
+        x = decoder_block(_sub(sd, f"layers.{j + 1}."), x, s, use_snake, nearest=nearest)
     x = _act(sd, f"layers.{n + 1}", x, use_snake)
     x = F.conv1d(x, wn_weight(sd, f"layers.{n + 2}"), None, padding=3)
     return torch.tanh(x) if final_tanh else x
@@ -460,9 +466,12 @@ def encoder_block_shapes(cin, cout, stride, use_snake, prefix=""):
     return s + _act_shapes(prefix + "layers.3", cin, use_snake) + _wnconv_shapes(prefix + "layers.4", cout, cin, 2 * stride)
 
 
-def decoder_block_shapes(cin, cout, stride, use_snake, prefix=""):
+def decoder_block_shapes(cin, cout, stride, use_snake, prefix="", nearest=False):
     s = _act_shapes(prefix + "layers.0", cin, use_snake)
-    s += _wnconv_shapes(prefix + "layers.1", cout, cin, 2 * stride + stride % 2, transposed=True)
+    if nearest:
+        s += _wnconv_shapes(prefix + "layers.1.1", cout, cin, 2 * stride, bias=False)
+    else:
+        s += _wnconv_shapes(prefix + "layers.1", cout, cin, 2 * stride + stride % 2, transposed=True)
     for i in range(3):
         s += residual_unit_shapes(cout, use_snake, f"{prefix}layers.{i + 2}.")
     return s
@@ -478,13 +487,13 @@ def oobleck_encoder_shapes(in_channels, channels, latent_dim, c_mults, strides, 
     return s + _wnconv_shapes(f"{prefix}layers.{n + 2}", latent_dim, cm[-1] * channels, 3)
 
 
-def oobleck_decoder_shapes(out_channels, channels, latent_dim, c_mults, strides, use_snake, prefix=""):
+def oobleck_decoder_shapes(out_channels, channels, latent_dim, c_mults, strides, use_snake, prefix="", nearest=False):
     cm = [1] + list(c_mults)
     s = _wnconv_shapes(prefix + "layers.0", cm[-1] * channels, latent_dim, 7)
     n = len(strides)
     for j, i in enumerate(range(n, 0, -1)):
         s += decoder_block_shapes(cm[i] * channels, cm[i - 1] * channels, strides[i - 1], use_snake,
-                                  f"{prefix}layers.{j + 1}.")
+                                  f"{prefix}layers.{j + 1}.", nearest=nearest)
     s += _act_shapes(f"{prefix}layers.{n + 1}", cm[0] * channels, use_snake)
     return s + _wnconv_shapes(f"{prefix}layers.{n + 2}", out_channels, cm[0] * channels, 7, bias=False)
 

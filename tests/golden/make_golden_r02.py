@@ -394,7 +394,39 @@ def vae_backward():
     save("vae_backward", **out)
 
 
-ALL = dict(vae_backward=vae_backward, chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
+def vae_nearest():
+    """DecoderBlock / OobleckDecoder with use_nearest_upsample=True (autoencoders.py:87-96: nn.Upsample(nearest) + a stride-1
+    WNConv1d of kernel 2*stride, no bias, padding='same' - an even kernel, so torch pads stride-1 left and stride right):
+    forward, input gradient, parameter-gradient digests; then the whole decoder forward + input gradient"""
+    from stable_audio_tools.models import autoencoders as ra
+    out = {}
+    B = 2
+    for snake in (True, False):
+        tag = "snake" if snake else "elu"
+        mod = load_seeded(ra.DecoderBlock(32, 16, stride=4, use_snake=snake, use_nearest_upsample=True), 31)
+        x = T(gu.make_input("x", (B, 32, 50), 131, 1.0)).requires_grad_(True)
+        y = mod(x)
+        dy = T(gu.make_input("dy", tuple(y.shape), 131))
+        y.backward(dy)
+        g = grads(mod)
+        out[f"{tag}/db/y"] = y
+        out[f"{tag}/db/dx"] = x.grad
+        out.update(digests(f"{tag}/db/", g, 16))
+        for k in list(g)[:3]:
+            out[f"{tag}/db/grad/{k}"] = g[k]
+        dec = load_seeded(ra.OobleckDecoder(out_channels=2, channels=8, latent_dim=4, c_mults=[1, 2, 4], strides=[2, 4, 5],
+                                            use_snake=snake, use_nearest_upsample=True, final_tanh=snake), 32)
+        z = T(gu.make_input("z", (B, 4, 37), 132, 1.0)).requires_grad_(True)
+        w = dec(z)
+        dw = T(gu.make_input("dw", tuple(w.shape), 132))
+        w.backward(dw)
+        out[f"{tag}/dec/y"] = w
+        out[f"{tag}/dec/dz"] = z.grad
+        out.update(digests(f"{tag}/dec/", grads(dec), 16))
+    save("vae_nearest", **out)
+
+
+ALL = dict(vae_nearest=vae_nearest, vae_backward=vae_backward, chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
            training_step=training_step, model_llasa=model_llasa)
 
 

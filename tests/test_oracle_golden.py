@@ -559,3 +559,25 @@ def test_vae_backward(snake):
     ((z * dz).sum() + (rec * drec).sum()).backward()
     close(wav.grad, f[f"{tag}/ae/dwav"], 5e-5)
     check_digests_n(f, sd, 16, prefix=f"{tag}/ae/", tol=2e-4)
+
+
+@pytest.mark.parametrize("snake", [True, False])
+def test_vae_nearest_upsample(snake):
+    """DecoderBlock / OobleckDecoder with use_nearest_upsample (autoencoders.py:87-96): sample repetition + an even-kernel
+    'same' convolution (stride-1 zeros left, stride right), forward and autograd against the reference"""
+    f = fx("vae_nearest")
+    tag = "snake" if snake else "elu"
+    sd = state(ko.decoder_block_shapes(32, 16, 4, snake, nearest=True), 31)
+    x = T(gu.make_input("x", (2, 32, 50), 131, 1.0), True)
+    y = ko.decoder_block(sd, x, 4, snake, nearest=True)
+    close(y, f[f"{tag}/db/y"], 1e-5)
+    y.backward(T(gu.make_input("dy", tuple(y.shape), 131)))
+    close(x.grad, f[f"{tag}/db/dx"], 2e-5)
+    check_digests_n(f, sd, 16, prefix=f"{tag}/db/", tol=1e-4)
+    sd = state(ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], snake, nearest=True), 32)
+    z = T(gu.make_input("z", (2, 4, 37), 132, 1.0), True)
+    w = ko.oobleck_decoder(sd, z, [2, 4, 5], snake, final_tanh=snake, nearest=True)
+    close(w, f[f"{tag}/dec/y"], 1e-5)
+    w.backward(T(gu.make_input("dw", tuple(w.shape), 132)))
+    close(z.grad, f[f"{tag}/dec/dz"], 5e-5)
+    check_digests_n(f, sd, 16, prefix=f"{tag}/dec/", tol=2e-4)

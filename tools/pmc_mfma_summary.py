@@ -13,7 +13,7 @@ for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recurs
         dur[name] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(dur.values())
 L = [f"# MFMA-pipe utilisation on the DiT path (rocprofv3 PMC, {TAG})\n",
-     "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
+     "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/bench_one_step.py 256 1` (2 steps of the bench workload)",
      "(its own pass, no other counters or traces).  SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe busy cycles summed over the 1024",
      "SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so clock = GUI_ACTIVE / 8 / kernel time and",
      "MFMA busy = BUSY_CYCLES / (GUI_ACTIVE / 8 x 1024).  The chip holds ~2.1 GHz under this load (2.4 GHz is what the 2.5 PFLOP/s",

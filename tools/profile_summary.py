@@ -23,7 +23,7 @@ for k, v in sorted(rf["all_gemm_variants"].items(), key=lambda kv: -kv[1]["time_
 L += ["", f"roofline kernel `{rf['kernel']}`: HIP events {rf['avg_launch_us']:.1f} us avg over {rf['launches']} launches (timed steps) = "
       f"{rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f} % of the 2.5 PFLOP/s dense-bf16 peak; the rocprof row of the same instantiation "
       "averages all profiled steps.", "",
-      f"HBM-side traffic (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, r01_pmc_hbm_traffic_b256.json; FETCH doubled per the gfx950 "
+      f"HBM-side traffic (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, {tag[:3]}_pmc_hbm_traffic_b256.json; FETCH doubled per the gfx950 "
       f"correction): {rf['traffic']/1e6:.0f} MB per launch vs {rf['algorithmic_bytes_per_launch']/1e6:.0f} MB algorithmic (operands once + output "
       "once). FETCH_SIZE counts L2 misses incl. Infinity-Cache hits, so the ratio is L2 re-fetch of the streamed panels, not DRAM traffic.",
       "", f"cpu_baseline: {json.dumps(bd.get('cpu_baseline'))}"]

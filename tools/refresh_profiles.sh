@@ -23,3 +23,15 @@ timeout -k 10 300 python tools/llasa_bench.py 16 1024 3 --infer > $O/llasa.log 2
 cp $(find $O/prof -name "*kernel_stats.csv" | head -n 1) $O/kernel_stats.csv
 rm -rf $O/prof
 echo done
+# PMC passes (each its own run, counters only + kernel trace): HBM-side fetch / write bytes and MFMA-pipe busy cycles
+if [ "$1" = "pmc" ]; then
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -- python3 $R/tools/bench_one_step.py 256 1 > $O/pmc_$C.log 2>&1 || exit 1
+    find $O/pmc_$C -type f ! -name "*counter_collection.csv" -delete
+  done
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/tools/bench_one_step.py 256 1 > $O/pmc_mfma.log 2>&1 || exit 1
+  find $O/pmc_mfma -type f ! -name "*counter_collection.csv" -delete
+  cd $R
+  echo pmc done
+fi
