@@ -731,6 +731,43 @@ def test_vae_backward_units_and_chain(dev, snake):
     assert not z2.requires_grad and rel(z2, z) < 1e-5
 
 
+@pytest.mark.parametrize("snake", [True, False])
+def test_vae_nearest_upsample_decoder(dev, snake):
+    """use_nearest_upsample (autoencoders.py:87-96): sample repetition (kalle_upsample_nearest) + a stride-1 conv with an even
+    kernel and torch's asymmetric 'same' padding; DecoderBlock and the whole decoder, training path (autograd units) against
+    the reference's forward / gradients, then the fused inference path against the same forward; fp32, rel-L2 <= 1e-4"""
+    import kalle_audio_amd
+    kalle_audio_amd.install()
+    from stable_audio_tools.models import autoencoders as A
+    f = fx("vae_nearest")
+    tag = "snake" if snake else "elu"
+    mod = load_seeded(A.DecoderBlock(32, 16, stride=4, use_snake=snake, use_nearest_upsample=True), 31, dev)
+    x = T(gu.make_input("x", (2, 32, 50), 131, 1.0), dev, True)
+    y = mod(x)
+    assert rel(y, f[f"{tag}/db/y"]) < 1e-4, rel(y, f[f"{tag}/db/y"])
+    y.backward(T(gu.make_input("dy", tuple(y.shape), 131), dev))
+    assert rel(x.grad, f[f"{tag}/db/dx"]) < 1e-4, rel(x.grad, f[f"{tag}/db/dx"])
+    g = {n: p.grad for n, p in mod.named_parameters()}
+    assert all(v is not None for v in g.values()), [n for n, v in g.items() if v is None]
+    check_digests(f, g, 16, prefix=f"{tag}/db/", tol=1e-3)
+    for k in f.files:
+        if k.startswith(f"{tag}/db/grad/"):
+            n = k[len(f"{tag}/db/grad/"):]
+            assert rel(g[n], f[k]) < 2e-4, (n, rel(g[n], f[k]))
+    dec = load_seeded(A.OobleckDecoder(out_channels=2, channels=8, latent_dim=4, c_mults=[1, 2, 4], strides=[2, 4, 5],
+                                       use_snake=snake, use_nearest_upsample=True, final_tanh=snake), 32, dev)
+    z = T(gu.make_input("z", (2, 4, 37), 132, 1.0), dev, True)
+    w = dec(z)
+    assert rel(w, f[f"{tag}/dec/y"]) < 1e-4, rel(w, f[f"{tag}/dec/y"])
+    w.backward(T(gu.make_input("dw", tuple(w.shape), 132), dev))
+    assert rel(z.grad, f[f"{tag}/dec/dz"]) < 2e-4, rel(z.grad, f[f"{tag}/dec/dz"])
+    check_digests(f, {n: p.grad for n, p in dec.named_parameters()}, 16, prefix=f"{tag}/dec/", tol=1e-3)
+    dec.requires_grad_(False)
+    with torch.no_grad():
+        w2 = dec(z.detach())
+    assert not w2.requires_grad and rel(w2, f[f"{tag}/dec/y"]) < 1e-4, rel(w2, f[f"{tag}/dec/y"])
+
+
 def test_training_step_with_enable_grad_pretransform(dev, monkeypatch):
     """training_step with pretransform.enable_grad: the diffusion loss reaches the VAE encoder through x_t AND the target
     (training/diffusion.py:343-346, 371-379); gradients against the CPU oracle's autograd on the same draws; and the trainer
