@@ -133,6 +133,19 @@ int kalle_rmsnorm_bwd_acc(const void* dy, int dy_dtype, const void* x, int x_dty
                           int rows_per_batch, const float* rrms, float* dx, float* dscale_acc, const float* dres,
                           void* dx_bf16, int rows, int D, void* stream);
 
+/* Attention(qk_norm=...) (transformer.py:303-307, 422-428): every 64-wide head of q / k is normalised before the rotary
+ * embedding.  mode 1 "l2": F.normalize = x / max(||x||_2, 1e-12);  mode 2 "ln": LayerNorm(64, eps 1e-6), gamma / beta fp32 [64].
+ * x, y: bf16 row-major with leading dimensions ldx / ldy and element offsets (the q or k slice of a projection output, as in
+ * kalle_attention_fwd; all multiples of 8); `heads` consecutive heads per row.  stat: fp32 [rows][heads][2], written by the
+ * forward (mean | clamp flag, reciprocal std | reciprocal norm) and read by the backward.
+ * Backward: g = gradient w.r.t. the normalised values (bf16, as kalle_attention_bwd leaves it), dx may alias g; mode 2 ADDS the
+ * column sums into dgamma / dbeta (fp32 [64], atomics; either may be NULL). */
+int kalle_head_norm_fwd(const void* x, int64_t ldx, int64_t x_off, void* y, int64_t ldy, int64_t y_off, float* stat,
+                        const float* gamma, const float* beta, int mode, int64_t rows, int heads, void* stream);
+int kalle_head_norm_bwd(const void* x, int64_t ldx, int64_t x_off, const float* stat, const void* g, int64_t ldg,
+                        int64_t g_off, void* dx, int64_t lddx, int64_t dx_off, const float* gamma, float* dgamma,
+                        float* dbeta, int mode, int64_t rows, int heads, void* stream);
+
 /* column sums: out[c] (+)= sum_r in[r][c]; in fp32 or bf16 [rows][ld]. Used for bias grads and partial reduces. */
 int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out, int rows, int cols, int accumulate,
                  void* stream);

@@ -383,6 +383,121 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ in
         else { CALL(8); }                        \
     } while (0)
 
+
+// ---- per-head normalisation of q / k before the rotary embedding (transformer.py:422-428, `qk_norm`):
+//   mode 1 "l2": F.normalize(x, dim=-1) = x / max(||x||, 1e-12);   mode 2 "ln": LayerNorm(64, eps 1e-6) with gamma / beta.
+// 8 lanes own one 64-wide head (8 bf16 each, one 16-byte load), sums are 3 xor-shuffles inside the 8-lane group.
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void head_norm_fwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y,
+                                                            int64_t ldy, float* __restrict__ stat, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int mode, int64_t rows, int heads) {
+    const int sub = threadIdx.x & 7;
+    const int64_t nunit = rows * heads;
+    float gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = 1.f; bt[e] = 0.f; }
+    if (mode == 2) {
+        load8<true>(gamma, sub * 8, gm);
+        if (beta) load8<true>(beta, sub * 8, bt);
+    }
+    for (int64_t u = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); u < nunit; u += (int64_t)gridDim.x * 32) {
+        const int64_t row = u / heads;
+        const int h = (int)(u - row * heads);
+        float v[8], o[8];
+        load8<false>(x, row * ldx + h * 64 + sub * 8, v);
+        float s = 0.f, mu = 0.f, rs;
+        if (mode == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e] * v[e];
+            const float nrm = sqrtf(group8_sum(s));
+            rs = 1.f / fmaxf(nrm, 1e-12f);
+            mu = nrm > 1e-12f ? 0.f : 1.f;          // 1: the clamp is active, the map is linear (x * 1e12)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[e] * rs;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+            mu = group8_sum(s) * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q += d * d; }
+            rs = rsqrtf(group8_sum(q) * (1.f / 64.f) + 1e-6f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu) * rs * gm[e] + bt[e];
+        }
+        store8<false>(y, row * ldy + h * 64 + sub * 8, o);
+        if (sub == 0) { stat[2 * u] = mu; stat[2 * u + 1] = rs; }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_norm_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ stat,
+                                                            const bf16_t* __restrict__ g, int64_t ldg, bf16_t* __restrict__ dx,
+                                                            int64_t lddx, const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int mode, int64_t rows, int heads) {
+    __shared__ float red[4][2][64];
+    const int sub = threadIdx.x & 7;
+    const int64_t nunit = rows * heads;
+    float gm[8], ag[8], ab[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = 1.f; ag[e] = 0.f; ab[e] = 0.f; }
+    if (mode == 2) load8<true>(gamma, sub * 8, gm);
+    for (int64_t u = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); u < nunit; u += (int64_t)gridDim.x * 32) {
+        const int64_t row = u / heads;
+        const int h = (int)(u - row * heads);
+        float v[8], gv[8], o[8];
+        load8<false>(x, row * ldx + h * 64 + sub * 8, v);
+        load8<false>(g, row * ldg + h * 64 + sub * 8, gv);
+        const float mu = stat[2 * u], rs = stat[2 * u + 1];
+        if (mode == 1) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += v[e] * rs * gv[e];
+            d = mu != 0.f ? 0.f : group8_sum(d);        // (every lane of the group takes the same branch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (gv[e] - v[e] * rs * d);
+        } else {
+            float s1 = 0.f, s2 = 0.f, xh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[e] = (v[e] - mu) * rs;
+                const float gh = gv[e] * gm[e];
+                s1 += gh;
+                s2 += gh * xh[e];
+                ag[e] += gv[e] * xh[e];
+                ab[e] += gv[e];
+            }
+            s1 = group8_sum(s1) * (1.f / 64.f);
+            s2 = group8_sum(s2) * (1.f / 64.f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rs * (gv[e] * gm[e] - s1 - xh[e] * s2);
+        }
+        store8<false>(dx, row * lddx + h * 64 + sub * 8, o);
+    }
+    if (mode != 2 || !dgamma) return;
+    // column sums of this workgroup: across the 8 groups of a wave by shuffles, across the 4 waves through LDS, one atomic per column
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = ag[e], b = ab[e];
+        a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 8); b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (lane < 8) { red[wave][0][lane * 8 + e] = a; red[wave][1][lane * 8 + e] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        float* dst = which ? dbeta : dgamma;
+        if (dst) atomicAdd(dst + c, t);
+    }
+}
+
 }  // namespace
 
 extern "C" int kalle_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
@@ -555,5 +670,33 @@ extern "C" int kalle_colsum(const void* in, int in_dtype, int64_t ld, float* out
         KALLE_LAUNCH((colsum_kernel<true>), grid, block, 0, st, in, ld, out, rows, cols, rps);
     else
         KALLE_LAUNCH((colsum_kernel<false>), grid, block, 0, st, in, ld, out, rows, cols, rps);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_head_norm_fwd(const void* x, int64_t ldx, int64_t x_off, void* y, int64_t ldy, int64_t y_off, float* stat,
+                                   const float* gamma, const float* beta, int mode, int64_t rows, int heads, void* stream) {
+    if (!x || !y || !stat || rows <= 0 || heads <= 0 || (mode != 1 && mode != 2) || (mode == 2 && !gamma)) return KALLE_ERR_ARG;
+    if ((ldx & 7) || (ldy & 7) || (x_off & 7) || (y_off & 7) || ldx < (int64_t)heads * 64 || ldy < (int64_t)heads * 64 || x_off < 0 ||
+        y_off < 0)
+        return KALLE_ERR_ARG;
+    const int64_t nunit = rows * heads;
+    const int grid = (int)((nunit + 31) / 32 < 4096 ? (nunit + 31) / 32 : 4096);
+    KALLE_LAUNCH(head_norm_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                 static_cast<const bf16_t*>(x) + x_off, ldx, static_cast<bf16_t*>(y) + y_off, ldy, stat, gamma, beta, mode, rows, heads);
+    return kalle_check_launch();
+}
+
+extern "C" int kalle_head_norm_bwd(const void* x, int64_t ldx, int64_t x_off, const float* stat, const void* g, int64_t ldg,
+                                   int64_t g_off, void* dx, int64_t lddx, int64_t dx_off, const float* gamma, float* dgamma,
+                                   float* dbeta, int mode, int64_t rows, int heads, void* stream) {
+    if (!x || !g || !dx || !stat || rows <= 0 || heads <= 0 || (mode != 1 && mode != 2) || (mode == 2 && !gamma)) return KALLE_ERR_ARG;
+    if ((ldx & 7) || (ldg & 7) || (lddx & 7) || (x_off & 7) || (g_off & 7) || (dx_off & 7) || x_off < 0 || g_off < 0 || dx_off < 0)
+        return KALLE_ERR_ARG;
+    if (ldx < (int64_t)heads * 64 || ldg < (int64_t)heads * 64 || lddx < (int64_t)heads * 64) return KALLE_ERR_ARG;
+    const int64_t nunit = rows * heads;
+    const int grid = (int)((nunit + 31) / 32 < 2048 ? (nunit + 31) / 32 : 2048);
+    KALLE_LAUNCH(head_norm_bwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                 static_cast<const bf16_t*>(x) + x_off, ldx, stat, static_cast<const bf16_t*>(g) + g_off, ldg,
+                 static_cast<bf16_t*>(dx) + dx_off, lddx, gamma, dgamma, dbeta, mode, rows, heads);
     return kalle_check_launch();
 }

@@ -141,47 +141,93 @@ def dgrad(dy, w, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, out_dtype=F32):
-    """transformer.py:419-420, 430-444, 500/514-530, 541-545.  h: bf16 [B*N, D]."""
+def qk_norm_params(attn):
+    """Attention(qk_norm=...) (transformer.py:303-307): None, or (mode, q gamma, q beta, k gamma, k beta) - mode 1 "l2" (no
+    parameters), 2 "ln" (two LayerNorm(64))"""
+    kind = getattr(attn, "qk_norm", "none")
+    if kind == "none":
+        return None
+    if kind == "l2":
+        return (1, None, None, None, None)
+    return (2, f32_of(attn.q_norm.weight), f32_of(attn.q_norm.bias), f32_of(attn.k_norm.weight), f32_of(attn.k_norm.bias))
+
+
+def _qk_norm_bwd(go, pre, qkn, which, x, ldx, x_off, stat, g, dx, lddx, dx_off, rows, heads):
+    """head-norm backward of q (`which` = "q_norm") or k; LayerNorm scale / bias gradients go to the sinks (added atomically)"""
+    mode = qkn[0]
+    gamma = dga = dbe = None
+    if mode == 2:
+        gamma = qkn[1] if which == "q_norm" else qkn[3]
+        dga = go.bias_acc(pre + which + ".weight", 64, x.device)
+        dbe = go.bias_acc(pre + which + ".bias", 64, x.device)
+    ops.head_norm_bwd(x, ldx, x_off, stat, g, dx, lddx, dx_off, rows, heads, mode, gamma, dga, dbe)
+
+
+def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, out_dtype=F32, qkn=None):
+    """transformer.py:419-420, 430-444, 500/514-530, 541-545.  h: bf16 [B*N, D].  qkn: qk_norm_params()"""
     D = H * 64
     qkv = ops.gemm(h, wqkv)
-    ao, lse = ops.attention_fwd(qkv, qkv, qkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D, ldv=3 * D, v_off=2 * D,
-                                B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+    nrm = None
+    if qkn is not None:     # :422-428, before the rotary embedding (which the attention kernel applies)
+        qn, qs = ops.head_norm_fwd(qkv, 3 * D, 0, B * N, H, qkn[0], qkn[1], qkn[2])
+        kn, ks = ops.head_norm_fwd(qkv, 3 * D, D, B * N, H, qkn[0], qkn[3], qkn[4])
+        nrm = (qn, qs, kn, ks)
+        ao, lse = ops.attention_fwd(qn, kn, qkv, ldq=D, q_off=0, ldk=D, k_off=0, ldv=3 * D, v_off=2 * D,
+                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+    else:
+        ao, lse = ops.attention_fwd(qkv, qkv, qkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D, ldv=3 * D, v_off=2 * D,
+                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
     out = ops.gemm(ao.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, gate=gate, rows_per_batch=N,
                    row_mask=mask8)
-    return out, (qkv, ao, lse)
+    return out, (qkv, ao, lse, nrm)
 
 
-def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_attn."):
+def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_attn.", qkn=None):
     """gb: bf16 [B*N, D] gradient w.r.t. the to_out GEMM result. Returns dh (bf16)."""
-    qkv, ao, lse = saved
+    qkv, ao, lse, nrm = saved
     D = H * 64
     go.wgrad(pre + "to_out.weight", gb, ao.view(B * N, D))
     dao = dgrad(gb, wo)
     dqkv = torch.empty_like(qkv)
-    ops.attention_bwd(qkv, qkv, qkv, ao, dao, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
-                      ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+    if nrm is not None:
+        qn, qs, kn, ks = nrm
+        dqn, dkn = torch.empty_like(qn), torch.empty_like(kn)
+        ops.attention_bwd(qn, kn, qkv, ao, dao, lse, dqn, dkn, dqkv, ldq=D, q_off=0, ldk=D, k_off=0,
+                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+        _qk_norm_bwd(go, pre, qkn, "q_norm", qkv, 3 * D, 0, qs, dqn, dqkv, 3 * D, 0, B * N, H)
+        _qk_norm_bwd(go, pre, qkn, "k_norm", qkv, 3 * D, D, ks, dkn, dqkv, 3 * D, D, B * N, H)
+    else:
+        ops.attention_bwd(qkv, qkv, qkv, ao, dao, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
+                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
     go.wgrad(pre + "to_qkv.weight", dqkv, h)
     return dgrad(dqkv, wqkv)
 
 
-def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None):
+def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None, qkn=None):
     """transformer.py:411-416, 505-508 (GQA), 541.  h: bf16 [B*N, D]; ctx: bf16 [B*S, Dc]."""
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
     q = ops.gemm(h, wq)
     kv = ops.gemm(ctx, wkv)
-    co, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
-                                Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+    nrm = None
+    if qkn is not None:
+        qn, qs = ops.head_norm_fwd(q, D, 0, B * N, H, qkn[0], qkn[1], qkn[2])
+        kn, ks = ops.head_norm_fwd(kv, 2 * Dc, 0, B * S, Hkv, qkn[0], qkn[3], qkn[4])
+        nrm = (qn, qs, kn, ks)
+        co, lse = ops.attention_fwd(qn, kn, kv, ldq=D, q_off=0, ldk=Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
+                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+    else:
+        co, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
+                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
     out = ops.gemm(co.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, row_mask=row_mask)
-    return out, (q, kv, co, lse)
+    return out, (q, kv, co, lse, nrm)
 
 
 def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_acc=None, want_dctx=True,
-                   pre="cross_attn."):
+                   pre="cross_attn.", qkn=None):
     """Returns dh (bf16), dctx (fp32 [B*S, Dc]; accumulated into dctx_acc when given; None if not wanted)."""
-    q, kv, co, lse = saved
+    q, kv, co, lse, nrm = saved
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
@@ -189,8 +235,16 @@ def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_
     dco = dgrad(gb, wo)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
-    ops.attention_bwd(q, kv, kv, co, dco, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
-                      v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+    if nrm is not None:
+        qn, qs, kn, ks = nrm
+        dkn = torch.empty_like(kn)
+        ops.attention_bwd(qn, kn, kv, co, dco, lse, dq, dkn, dkv, ldq=D, q_off=0, ldk=Dc, k_off=0, ldv=2 * Dc,
+                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+        _qk_norm_bwd(go, pre, qkn, "q_norm", q, D, 0, qs, dq, dq, D, 0, B * N, H)          # in place over dq
+        _qk_norm_bwd(go, pre, qkn, "k_norm", kv, 2 * Dc, 0, ks, dkn, dkv, 2 * Dc, 0, B * S, Hkv)
+    else:
+        ops.attention_bwd(q, kv, kv, co, dco, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
+                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
     go.wgrad(pre + "to_q.weight", dq, h)
     dh = dgrad(dq, wq)
     go.wgrad(pre + "to_kv.weight", dkv, ctx)
@@ -265,13 +319,18 @@ def block_params(blk):
     if p.ada:
         p.wmod = bf16_of(blk.to_scale_shift_gate[1].weight)
     p.H = blk.dim // blk.dim_heads
+    p.qkn_s = qk_norm_params(blk.self_attn)
+    p.qkn_c = qk_norm_params(blk.cross_attn) if p.cross else None
     return p
 
 
 BLOCK_PARAM_ORDER = ("pre_norm.gamma", "self_attn.to_qkv.weight", "self_attn.to_out.weight",
                      "cross_attend_norm.gamma", "cross_attn.to_q.weight", "cross_attn.to_kv.weight",
                      "cross_attn.to_out.weight", "ff_norm.gamma", "ff.ff.0.proj.weight", "ff.ff.0.proj.bias",
-                     "ff.ff.2.weight", "ff.ff.2.bias", "to_scale_shift_gate.1.weight")
+                     "ff.ff.2.weight", "ff.ff.2.bias", "to_scale_shift_gate.1.weight",
+                     "self_attn.q_norm.weight", "self_attn.q_norm.bias", "self_attn.k_norm.weight", "self_attn.k_norm.bias",
+                     "cross_attn.q_norm.weight", "cross_attn.q_norm.bias", "cross_attn.k_norm.weight",
+                     "cross_attn.k_norm.bias")
 
 
 def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
@@ -289,13 +348,13 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
         sc_s, sh_s, g_s, sc_f, sh_f, g_f = (sv.mod[:, i * D:(i + 1) * D] for i in range(6))
     # self-attention
     sv.h1, sv.mean1, sv.rstd1 = ops.layernorm_fwd(x, p.g1, p.beta1, sc_s, sh_s, rows_per_batch=N)
-    sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s)
+    sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s, qkn=p.qkn_s)
     xcur = sv.x1
     # cross-attention (never modulated, 670-671)
     sv.has_cross = p.cross and ctx is not None
     if sv.has_cross:
         sv.h2, sv.mean2, sv.rstd2 = ops.layernorm_fwd(xcur, p.g2, p.beta2)
-        sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur)
+        sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur, qkn=p.qkn_c)
         xcur = sv.x2
     # feed-forward
     sv.h3, sv.mean3, sv.rstd3 = ops.layernorm_fwd(xcur, p.g3, p.beta3, sc_f, sh_f, rows_per_batch=N)
@@ -336,7 +395,7 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
     dctx = None
     if sv.has_cross:
         dh2, dctx = cross_attn_bwd(go, g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc,
-                                   want_dctx)
+                                   want_dctx, qkn=p.qkn_c)
         g1, g1bf = go.ln("cross_attend_norm.gamma", dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2,
                          want_bf16=not ada and mask8 is None)
     else:
@@ -349,7 +408,7 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         g1b, _ = ops.grad_cast(g1, B, N, row_mask=mask8)
     else:
         g1b = g1bf if g1bf is not None else ops.cast(g1, BF16)
-    dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8)
+    dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8, qkn=p.qkn_s)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
         dsl(0).copy_(dsc)

@@ -392,11 +392,12 @@ class AttentionFn(torch.autograd.Function):
             cb = _to_bf16(kv_in.contiguous()).view(B * S, kv_in.shape[-1])
             km = cmask8 if context is not None else mask8
             out, sv = D.cross_attn_fwd(h, cb, D.bf16_of(mod.to_q.weight), D.bf16_of(mod.to_kv.weight),
-                                       D.bf16_of(mod.to_out.weight), B, N, S, H, km, out_dtype=odt, row_mask=mask8)
+                                       D.bf16_of(mod.to_out.weight), B, N, S, H, km, out_dtype=odt, row_mask=mask8,
+                                       qkn=D.qk_norm_params(mod))
             ctx.extra = (cb, S, km, context is not None)
         else:
             out, sv = D.self_attn_fwd(h, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight), B, N, H, rope,
-                                      mask8, out_dtype=odt)
+                                      mask8, out_dtype=odt, qkn=D.qk_norm_params(mod))
             ctx.extra = None
         ctx.mod, ctx.h, ctx.sv, ctx.cross = mod, h, sv, cross
         ctx.meta = (B, N, Dm, H, mask8, rope, x.dtype, context.dtype if context is not None else None,
@@ -417,7 +418,7 @@ class AttentionFn(torch.autograd.Function):
             go = D.GradOut()
             dh, dctx = D.cross_attn_bwd(go, gb, ctx.h, cb, ctx.sv, D.bf16_of(mod.to_q.weight),
                                         D.bf16_of(mod.to_kv.weight), D.bf16_of(mod.to_out.weight), B, N, S, H, km,
-                                        pre="")
+                                        pre="", qkn=D.qk_norm_params(mod))
             dwq, dwkv, dwo = go.grads["to_q.weight"], go.grads["to_kv.weight"], go.grads["to_out.weight"]
             dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
             dc = None
@@ -425,13 +426,20 @@ class AttentionFn(torch.autograd.Function):
                 dc = dctx.view(cshape).to(cdt)
             else:
                 dx = dx + dctx.view(B, N, Dm).to(dx.dtype)  # kv_input == x: tape-level add of two input gradients
-            return (None, dx, dc, None, None, None, dwq, dwkv, dwo)
+            return (None, dx, dc, None, None, None, dwq, dwkv, dwo) + _qk_norm_grads(mod, go)
         go = D.GradOut()
         dh = D.self_attn_bwd(go, gb, ctx.h, ctx.sv, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight),
-                             B, N, H, rope, mask8, pre="")
+                             B, N, H, rope, mask8, pre="", qkn=D.qk_norm_params(mod))
         dwqkv, dwo = go.grads["to_qkv.weight"], go.grads["to_out.weight"]
         dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
-        return (None, dx, None, None, None, None, dwqkv, dwo)
+        return (None, dx, None, None, None, None, dwqkv, dwo) + _qk_norm_grads(mod, go)
+
+
+def _qk_norm_grads(mod, go):
+    """gradients of Attention(qk_norm="ln")'s two LayerNorm(64), in the order Attention.forward appends the parameters"""
+    if getattr(mod, "qk_norm", "none") != "ln":
+        return ()
+    return tuple(go.grads[n] for n in ("q_norm.weight", "q_norm.bias", "k_norm.weight", "k_norm.bias"))
 
 
 class FeedForwardFn(torch.autograd.Function):

@@ -397,6 +397,23 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, ldq, q_off, ldk, k_off
                                   int(causal), B, H, Hkv, Nq, Nk, _stream()), "kalle_attention_bwd")
 
 
+def head_norm_fwd(x, ldx, x_off, rows, heads, mode, gamma=None, beta=None):
+    """qk_norm (transformer.py:422-428) on the q or k slice of a projection output: returns (y bf16 [rows, heads*64], stat)"""
+    lib = _lib.load()
+    y = torch.empty((rows, heads * 64), device=x.device, dtype=torch.bfloat16)
+    stat = torch.empty((rows, heads, 2), device=x.device, dtype=torch.float32)
+    check(lib.kalle_head_norm_fwd(_p(x), ldx, x_off, _p(y), heads * 64, 0, _p(stat), _p(gamma), _p(beta), mode, rows, heads,
+                                  _stream()), "kalle_head_norm_fwd")
+    return y, stat
+
+
+def head_norm_bwd(x, ldx, x_off, stat, g, dx, lddx, dx_off, rows, heads, mode, gamma=None, dgamma=None, dbeta=None):
+    """g: bf16 [rows, heads*64] gradient w.r.t. the normalised values; writes the gradient w.r.t. x into dx (ld / offset)"""
+    lib = _lib.load()
+    check(lib.kalle_head_norm_bwd(_p(x), ldx, x_off, _p(stat), _p(g), heads * 64, 0, _p(dx), lddx, dx_off, _p(gamma),
+                                  _p(dgamma), _p(dbeta), mode, rows, heads, _stream()), "kalle_head_norm_bwd")
+
+
 # ------------------------------------------------------------------------------------------------ Llasa head / tail
 def peak_normalize_int16(x):
     """int16(clamp(x / max|x|, -1, 1) * 32767) (infer_0723.py:293); returns (int16 tensor of x's shape, peak [1] fp32)"""

@@ -2,7 +2,7 @@
 constructor kwargs, forward signatures and state-dict keys; every forward runs the hand-written gfx950 kernels
 (kalle_audio_amd/csrc) through autograd shims.  GPU tensors only - there is no CPU or torch-math fallback.
 
-Not carried over (raise NotImplementedError when requested): causal attention, qk_norm, natten neighbourhood
+Not carried over (raise NotImplementedError when requested): causal attention, natten neighbourhood
 attention, conv feed-forward, ConformerModule, sinusoidal/absolute position embeddings - none is reachable from
 the DiT path (dit.py:107-125) with the configs the reference ships.
 """
@@ -108,8 +108,10 @@ class Attention(nn.Module):
     def __init__(self, dim, dim_heads=64, dim_context=None, causal=False, zero_init_output=True, qk_norm='none',
                  natten_kernel_size=None):
         super().__init__()
-        if causal or qk_norm != 'none' or natten_kernel_size is not None:
-            raise NotImplementedError("Attention(causal / qk_norm / natten): not on the DiT path (dit.py:252)")
+        if causal or natten_kernel_size is not None:
+            raise NotImplementedError("Attention(causal / natten): not on the DiT path (dit.py:252)")
+        if qk_norm not in ("none", "l2", "ln"):
+            raise ValueError(f"unknown qk_norm {qk_norm!r}")
         if dim_heads != 64:
             raise NotImplementedError("the fused attention kernel is specialised for head dim 64")
         self.dim = dim
@@ -127,6 +129,9 @@ class Attention(nn.Module):
         if zero_init_output:
             nn.init.zeros_(self.to_out.weight)
         self.qk_norm = qk_norm
+        if qk_norm == "ln":         # transformer.py:305-307
+            self.q_norm = nn.LayerNorm(dim_heads, elementwise_affine=True, eps=1.0e-6)
+            self.k_norm = nn.LayerNorm(dim_heads, elementwise_affine=True, eps=1.0e-6)
         self.natten_kernel_size = natten_kernel_size
 
     def forward(self, x, context=None, mask=None, context_mask=None, rotary_pos_emb=None, causal=None):
@@ -141,6 +146,8 @@ class Attention(nn.Module):
             params = (self.to_q.weight, self.to_kv.weight, self.to_out.weight)
         else:
             params = (self.to_qkv.weight, self.to_out.weight)
+        if self.qk_norm == "ln":
+            params += (self.q_norm.weight, self.q_norm.bias, self.k_norm.weight, self.k_norm.bias)
         return KF.AttentionFn.apply(self, x, context, KF._mask8(mask), KF._mask8(context_mask), rope, *params)
 
 

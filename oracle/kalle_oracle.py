@@ -80,7 +80,7 @@ def _sub(sd, prefix):
 
 
 # ---------------------------------------------------------------------------------------------- attention / FF
-def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, dim_heads=64):
+def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, dim_heads=64, qk_l2=False):
     """transformer.py:396-547 (einsum / fp32-softmax branch 502-530, which is what the reference runs on CPU).
     sd keys: to_qkv.weight | to_q.weight,to_kv.weight ; to_out.weight"""
     B, N, D = x.shape
@@ -96,6 +96,12 @@ def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, di
     q = q.view(B, N, h, dim_heads).transpose(1, 2)
     k = k.reshape(B, -1, kv_h, dim_heads).transpose(1, 2)
     v = v.reshape(B, -1, kv_h, dim_heads).transpose(1, 2)
+    if "q_norm.weight" in sd:                         # 426-428 qk_norm == "ln": LayerNorm(dim_heads, eps 1e-6) per head
+        q = F.layer_norm(q, (dim_heads,), sd["q_norm.weight"], sd["q_norm.bias"], 1e-6)
+        k = F.layer_norm(k, (dim_heads,), sd["k_norm.weight"], sd["k_norm.bias"], 1e-6)
+    elif qk_l2:                                       # 423-425 qk_norm == "l2": x / max(||x||, 1e-12)
+        q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        k = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     if rotary is not None and context is None:       # 430-444: self-attention only
         q = apply_rotary(q.float(), rotary)
         k = apply_rotary(k.float(), rotary)
@@ -123,7 +129,8 @@ def feed_forward(sd, x):
     return linear(a * F.silu(g), sd["ff.2.weight"], sd["ff.2.bias"])
 
 
-def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_mask=None, rotary=None, dim_heads=64):
+def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_mask=None, rotary=None, dim_heads=64,
+                      qk_l2=False):
     """transformer.py:649-695.  adaLN branch when the block has to_scale_shift_gate and global_cond is given."""
     ln = lambda pre, t: layer_norm(t, sd[pre + ".gamma"], sd.get(pre + ".beta"))
     sa = _sub(sd, "self_attn.")
@@ -133,19 +140,19 @@ def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_
         sc_s, sh_s, g_s, sc_f, sh_f, g_f = mod.chunk(6, -1)
         res = x
         hx = ln("pre_norm", x) * (1 + sc_s) + sh_s
-        hx = attention(sa, hx, mask=mask, rotary=rotary, dim_heads=dim_heads)
+        hx = attention(sa, hx, mask=mask, rotary=rotary, dim_heads=dim_heads, qk_l2=qk_l2)
         x = hx * torch.sigmoid(1 - g_s) + res
         if context is not None:
             x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
-                              context_mask=context_mask, dim_heads=dim_heads)
+                              context_mask=context_mask, dim_heads=dim_heads, qk_l2=qk_l2)
         res = x
         hx = ln("ff_norm", x) * (1 + sc_f) + sh_f
         x = feed_forward(ff, hx) * torch.sigmoid(1 - g_f) + res
     else:
-        x = x + attention(sa, ln("pre_norm", x), mask=mask, rotary=rotary, dim_heads=dim_heads)
+        x = x + attention(sa, ln("pre_norm", x), mask=mask, rotary=rotary, dim_heads=dim_heads, qk_l2=qk_l2)
         if context is not None:
             x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
-                              context_mask=context_mask, dim_heads=dim_heads)
+                              context_mask=context_mask, dim_heads=dim_heads, qk_l2=qk_l2)
         x = x + feed_forward(ff, ln("ff_norm", x))
     return x
 
@@ -391,14 +398,15 @@ def pretransform_decode(sd, z, strides, use_snake, scale=1.0, final_tanh=True):
 
 
 # ---------------------------------------------------------------------------------------------- parameter shapes
-def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix=""):
-    """(name, shape) list of one TransformerBlock (transformer.py:585-647)"""
+def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix="", qk_ln=False):
+    """(name, shape) list of one TransformerBlock (transformer.py:585-647); qk_ln: Attention(qk_norm="ln")'s LayerNorms"""
+    qkn = lambda a: [(f"{prefix}{a}.{n}.{w}", (dim_heads,)) for n in ("q_norm", "k_norm") for w in ("weight", "bias")] if qk_ln else []
     s = [(prefix + "pre_norm.gamma", (D,)), (prefix + "self_attn.to_qkv.weight", (3 * D, D)),
-         (prefix + "self_attn.to_out.weight", (D, D))]
+         (prefix + "self_attn.to_out.weight", (D, D))] + qkn("self_attn")
     if dim_context is not None:
         s += [(prefix + "cross_attend_norm.gamma", (D,)), (prefix + "cross_attn.to_q.weight", (D, D)),
               (prefix + "cross_attn.to_kv.weight", (2 * dim_context, dim_context)),
-              (prefix + "cross_attn.to_out.weight", (D, D))]
+              (prefix + "cross_attn.to_out.weight", (D, D))] + qkn("cross_attn")
     s += [(prefix + "ff_norm.gamma", (D,)), (prefix + "ff.ff.0.proj.weight", (8 * D, D)),
           (prefix + "ff.ff.0.proj.bias", (8 * D,)), (prefix + "ff.ff.2.weight", (D, 4 * D)),
           (prefix + "ff.ff.2.bias", (D,))]

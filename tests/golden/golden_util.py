@@ -114,6 +114,7 @@ def llasa_batch(lc, seed, B=3, L=40):
 # round-2 fixtures --------------------------------------------------------------------------------------------------------
 # bench-width TransformerBlock (D = 1536, 24 heads, context 768 = 12 kv heads, 126 tokens, 130 context tokens)
 WIDE_BLOCK = dict(D=1536, DC=768, N=126, S=130, B=1)
+QK_NORM_BLOCK = dict(D=256, DC=128, N=40, S=24, B=2)
 
 # Llasa at 4 heads / 2 kv heads, sequences of ~300 with ragged right padding (30 s clips of configs/twj_0828.yaml are
 # 375 frames + text)

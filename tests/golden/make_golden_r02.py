@@ -94,6 +94,39 @@ def wide_blocks():
         save(name, y=f16(y), dx=f16(x.grad), dctx=f16(ctx.grad), **extra, **digests("", grads(blk), 64))
 
 
+def block_qk_norm():
+    """TransformerBlock(attn_kwargs={"qk_norm": "l2" | "ln"}) (transformer.py:303-307, 422-428): q and k normalised per head
+    before the rotary embedding, self-attention (4 heads) and GQA cross-attention (4 over 2 kv heads, ragged context mask);
+    "ln" on an adaLN block.  Outputs, input gradients, parameter-gradient digests, the LayerNorm(64) gradients in full."""
+    from stable_audio_tools.models import transformer as rt
+    q = gu.QK_NORM_BLOCK
+    D, DC, N, S, B = q["D"], q["DC"], q["N"], q["S"], q["B"]
+    rot = rt.RotaryEmbedding(32)
+    out = {}
+    for kind, gdim, seed in (("l2", None, 70), ("ln", D, 71)):
+        x = T(gu.make_input("x", (B, N, D), seed)).requires_grad_(True)
+        ctx = T(gu.make_input("ctx", (B, S, DC), seed)).requires_grad_(True)
+        dy = T(gu.make_input("dy", (B, N, D), seed))
+        cmask = torch.arange(S)[None, :] < torch.tensor([S, S - 7])[:, None]
+        blk = load_seeded(rt.TransformerBlock(D, dim_heads=64, cross_attend=True, dim_context=DC, global_cond_dim=gdim,
+                                              attn_kwargs={"qk_norm": kind}), seed)
+        kw = {}
+        if gdim:
+            gc = T(gu.make_input("g", (B, D), seed)).requires_grad_(True)
+            kw["global_cond"] = gc
+        y = blk(x, context=ctx, context_mask=cmask, rotary_pos_emb=rot.forward_from_seq_len(N), **kw)
+        y.backward(dy)
+        g = grads(blk)
+        out[f"{kind}/y"], out[f"{kind}/dx"], out[f"{kind}/dctx"] = y, x.grad, ctx.grad
+        if gdim:
+            out[f"{kind}/dg"] = gc.grad
+        out.update(digests(f"{kind}/", g, 32))
+        for k in g:
+            if "_norm." in k and "attn" in k:
+                out[f"{kind}/grad/{k}"] = g[k]
+    save("block_qk_norm", **out)
+
+
 def dit_long():
     from stable_audio_tools.models.dit import DiffusionTransformer
     from stable_audio_tools.training.losses.losses import MSELoss, MultiLoss
@@ -426,7 +459,7 @@ def vae_nearest():
     save("vae_nearest", **out)
 
 
-ALL = dict(vae_nearest=vae_nearest, vae_backward=vae_backward, chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
+ALL = dict(block_qk_norm=block_qk_norm, vae_nearest=vae_nearest, vae_backward=vae_backward, chunked_vae=chunked_vae, wide_blocks=wide_blocks, dit_long=dit_long, llasa_wide=llasa_wide, generate_e2e=generate_e2e,
            training_step=training_step, model_llasa=model_llasa)
 
 

@@ -122,11 +122,26 @@ def test_unsupported_reference_options_raise():
     from kalle_audio_amd.stable_audio_tools.models import transformer as T
     from kalle_audio_amd.stable_audio_tools.models.dit import DiffusionTransformer
     with pytest.raises(NotImplementedError):
-        T.Attention(128, qk_norm="ln")
+        T.Attention(128, causal=True)
+    with pytest.raises(ValueError):
+        T.Attention(128, qk_norm="rms")
     with pytest.raises(NotImplementedError):
         T.TransformerBlock(128, conformer=True)
     with pytest.raises(NotImplementedError):
         DiffusionTransformer(transformer_type="x-transformers")
+
+
+def test_optional_variants_keep_the_reference_parameter_names():
+    """Attention(qk_norm="ln") and DecoderBlock(use_nearest_upsample=True): the parameter names / shapes of the reference's
+    modules (transformer.py:305-307 q_norm / k_norm LayerNorm(64); autoencoders.py:87-96 layers.1.1.weight_{g,v}, no bias)"""
+    from kalle_audio_amd.stable_audio_tools.models import transformer as T
+    from kalle_audio_amd.stable_audio_tools.models.autoencoders import DecoderBlock
+    a = dict(T.Attention(128, dim_context=64, qk_norm="ln").named_parameters())
+    assert {k: tuple(v.shape) for k, v in a.items() if "_norm" in k} == {
+        "q_norm.weight": (64,), "q_norm.bias": (64,), "k_norm.weight": (64,), "k_norm.bias": (64,)}
+    assert not any("_norm" in k for k, _ in T.Attention(128, qk_norm="l2").named_parameters())
+    d = {k: tuple(v.shape) for k, v in DecoderBlock(32, 16, stride=4, use_nearest_upsample=True).named_parameters()}
+    assert d["layers.1.1.weight_v"] == (16, 32, 8) and d["layers.1.1.weight_g"] == (16, 1, 1) and "layers.1.1.bias" not in d
 
 
 def test_reference_yaml_and_accelerate_configs_parse():

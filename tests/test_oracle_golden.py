@@ -254,11 +254,13 @@ def test_llasa():
 
 
 # ------------------------------------------------------------------------------------------------ round-2 fixtures
-def check_digests_n(f, sd, n, prefix="", tol=5e-5, strip=""):
+def check_digests_n(f, sd, n, prefix="", tol=5e-5, strip="", skip=()):
     cnt = 0
     for k in f.files:
         if k.startswith(prefix + "digest/"):
             name = k[len(prefix) + 7:]
+            if name in skip:
+                continue
             key = name[len(strip):] if strip and name.startswith(strip) else name
             got = gu.digest(sd[key].grad.numpy(), n)
             ref = f[k]
@@ -581,3 +583,34 @@ def test_vae_nearest_upsample(snake):
     w.backward(T(gu.make_input("dw", tuple(w.shape), 132)))
     close(z.grad, f[f"{tag}/dec/dz"], 5e-5)
     check_digests_n(f, sd, 16, prefix=f"{tag}/dec/", tol=2e-4)
+
+
+@pytest.mark.parametrize("kind,ada,seed", [("l2", False, 70), ("ln", True, 71)])
+def test_transformer_block_qk_norm(kind, ada, seed):
+    """Attention(qk_norm=...) (transformer.py:303-307, 422-428) inside a TransformerBlock: per-head F.normalize / LayerNorm(64)
+    of q and k before the rotary embedding; self-attention + GQA cross-attention with a ragged context mask"""
+    f = fx("block_qk_norm")
+    q = gu.QK_NORM_BLOCK
+    Dq, DCq, Nq, Sq, Bq = q["D"], q["DC"], q["N"], q["S"], q["B"]
+    x = T(gu.make_input("x", (Bq, Nq, Dq), seed), True)
+    ctx = T(gu.make_input("ctx", (Bq, Sq, DCq), seed), True)
+    dy = T(gu.make_input("dy", (Bq, Nq, Dq), seed))
+    cmask = torch.arange(Sq)[None, :] < torch.tensor([Sq, Sq - 7])[:, None]
+    sd = state(ko.block_shapes(Dq, dim_context=DCq, global_cond_dim=Dq if ada else None, qk_ln=kind == "ln"), seed)
+    gc = T(gu.make_input("g", (Bq, Dq), seed), True) if ada else None
+    y = ko.transformer_block(sd, x, context=ctx, context_mask=cmask, global_cond=gc, rotary=ko.rotary_freqs(Nq),
+                             qk_l2=kind == "l2")
+    y.backward(dy)
+    close(y, f[f"{kind}/y"], 1e-5); close(x.grad, f[f"{kind}/dx"], 2e-5); close(ctx.grad, f[f"{kind}/dctx"], 2e-5)
+    if ada:
+        close(gc.grad, f[f"{kind}/dg"], 2e-5)
+    # a bias on every key of an un-rotated attention shifts each query's logits by a constant: its gradient is zero up to rounding
+    zero = "cross_attn.k_norm.bias"
+    check_digests_n(f, sd, 32, prefix=f"{kind}/", tol=1e-4, skip=(zero,))
+    for k in f.files:
+        if k.startswith(f"{kind}/grad/"):
+            name = k[len(kind) + 6:]
+            if name == zero:
+                assert np.abs(f[k]).max() < 1e-4 and sd[name].grad.abs().max() < 1e-4
+            else:
+                close(sd[name].grad, f[k], 5e-5)
