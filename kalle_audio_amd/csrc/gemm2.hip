@@ -1171,8 +1171,8 @@ extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int n
         double best = 1e30;
         for (int u = 0;; u += 256) {
             const int ut = u < ntot ? u : ntot;
-            for (int sp = 1; sp <= 12 && (sp == 1 || min_nk / sp >= 8); ++sp) {
-                if (ut == ntot && sp > 1) break;
+            // (one slice per tile IS a whole tile, only through the atomic path: sp = 1 belongs to ut == ntot alone)
+            for (int sp = ut == ntot ? 1 : 2; sp <= 12 && (sp == 1 || min_nk / sp >= 8); ++sp) {
                 const double t = replay_group(gp.pr, nprob, ut, sp);
                 if (t < best * 0.995) { best = t; plan.unsplit_total = ut; plan.splits = sp; }
             }
@@ -1182,6 +1182,7 @@ extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int n
         else { cache[victim] = plan; victim = (victim + 1) & 15; }
     }
     if (min_nk / plan.splits < 1) plan.splits = 1;
+    if (plan.splits == 1) plan.unsplit_total = ntot;
     int left = plan.unsplit_total, b1 = 0;
     for (int i = 0; i < nprob; ++i) {
         GroupProblem& q = gp.pr[i];
