@@ -422,6 +422,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
 
+    if (!(p.dbg & 2)) {      // (debug knob: bit 1 skips the pipeline, bit 0 the stores - tools/skinny_knockout.sh)
     // prologue: up to three tiles in flight (3-stage ring), wait for tile 0 only
     constexpr int PT = Loader<A_KM, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;   // DMA pieces per tile per wave
     la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
@@ -497,6 +498,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     if (kt + 2 < nk) { iteration(F_{}, T_{}, T_{}); ++kt; }
     if (kt + 1 < nk) { iteration(F_{}, T_{}, F_{}); ++kt; }
     iteration(F_{}, F_{}, F_{});
+    }
+    if (p.dbg & 1) return;
 
     if constexpr (C_F32) {
         if (p.slab_stride) {        // split-K into per-slice slabs (few-rows path)
@@ -781,7 +784,8 @@ int kalle_gemm_v2_launch(GemmParams& p, bool a_km, bool b_km, bool f32, hipStrea
     if (p.K & 7) return KALLE_ERR_UNSUPPORTED;        // (a ragged last K-tile is fine: K % 64 in multiples of 8)
     if (a_km && !b_km) return KALLE_ERR_UNSUPPORTED;
     if (a_km && !f32) return KALLE_ERR_UNSUPPORTED;
-    if (p.M < 256 || p.N < 128) return KALLE_ERR_UNSUPPORTED;
+    static const int min_m = getenv("KALLE_V2_MIN_M") ? atoi(getenv("KALLE_V2_MIN_M")) : 256;
+    if (p.M < min_m || p.N < 128) return KALLE_ERR_UNSUPPORTED;
     if (a_km && (p.M & 7)) return KALLE_ERR_UNSUPPORTED;
     const int nk = (p.K + BK2 - 1) / BK2;
     if (p.glu_mode) {
@@ -1000,7 +1004,8 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     constexpr int bn = 128;
     const int tiles = ((pin.M + 255) / 256) * ((pin.N + bn - 1) / bn);
     if (tiles >= 192) return KALLE_ERR_UNSUPPORTED;                 // enough output tiles on their own
-    int splits = (320 + tiles - 1) / tiles;                          // ~1.25 workgroups per CU
+    static const int target = getenv("KALLE_FEW_ROWS_TARGET") ? atoi(getenv("KALLE_FEW_ROWS_TARGET")) : 320;
+    int splits = (target + tiles - 1) / tiles;                       // ~1.25 workgroups per CU
     // at least two K-tiles per slice; with more than a couple of tile rows (training at small batch) a slice must be long
     // enough (16 K-tiles) to pay for its slab: M x N x 4 bytes written and read back per slice
     const int min_per = pin.M > 512 ? 16 : 2;
@@ -1021,6 +1026,8 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     q.ktiles_per_split = (nk + splits - 1) / splits;
     q.splits = (nk + q.ktiles_per_split - 1) / q.ktiles_per_split;
     q.slab_stride = slab;
+    static const int dbg = getenv("KALLE_FEW_ROWS_DBG") ? atoi(getenv("KALLE_FEW_ROWS_DBG")) : 0;
+    q.dbg = dbg;
     const int rc = b_km ? launch2<false, true, true, 4, 2, 4>(q, st) : launch2<false, false, true, 4, 2, 4>(q, st);
     if (rc != KALLE_OK) return rc;
     GemmParams f = pin;
