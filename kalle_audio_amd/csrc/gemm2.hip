@@ -55,7 +55,7 @@ struct Loader {
                 int gr = min(r0 + row, Rtot - 1);                           // clamp: rows >= Rtot are never stored
                 if (glu_inner > 0) {
                     const int wn_ = row >> 6, w_ = row & 63;
-                    gr = (w_ >= 32 ? glu_inner : 0) + glu_tn * 128 + wn_ * 32 + (w_ & 31);
+                    gr = (w_ >= 32 ? glu_inner : 0) + glu_tn * (R / 2) + wn_ * 32 + (w_ & 31);
                 }
                 src[i] = X + (int64_t)gr * ld + k0 + 8 * c;
             } else {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
                                                               __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
 
-template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
+template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM, int GLU = 0, int NS = 3>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     static_assert(TM == 4, "wave tile is 64 x 64");
     constexpr int TN = 4;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     Loader<A_KM, BM, NW> la;
     Loader<B_KM, BN, NW> lb;
     la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
-    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane);
+    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
     const int arow = wm * TM * 16, bcol = wn * TN * 16;
     Reader<A_KM, BM> ra;
     Reader<B_KM, BN> rb;
@@ -423,22 +423,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     rb.init(lds0 + A_BYTES, bcol, lane);
 
     if (!(p.dbg & 2)) {      // (debug knob: bit 1 skips the pipeline, bit 0 the stores - tools/skinny_knockout.sh)
-    // prologue: up to three tiles in flight (3-stage ring), wait for tile 0 only
+    // prologue: up to NS tiles in flight (ring of NS stages); wait for tile 0 (for tile 1 too where the 6-bit vmcnt could not
+    // name NS - 1 tiles)
     constexpr int PT = Loader<A_KM, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;   // DMA pieces per tile per wave
-    la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
-    lb.issue_at(smem + A_BYTES, wave, lane, 0, tail_t, kvalid);
-    if (nk > 1) {
-        la.issue_at(smem + STAGE, wave, lane, 1, tail_t, kvalid);
-        lb.issue_at(smem + STAGE + A_BYTES, wave, lane, 1, tail_t, kvalid);
-    }
-    if (nk > 2) {
-        la.issue_at(smem + 2 * STAGE, wave, lane, 2, tail_t, kvalid);
-        lb.issue_at(smem + 2 * STAGE + A_BYTES, wave, lane, 2, tail_t, kvalid);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PT) : "memory");
-    } else if (nk > 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert((NS - 2) * PT <= 63, "vmcnt is a 6-bit counter");
+    {
+        const int pre = nk < NS ? nk : NS;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (t < pre) {
+                la.issue_at(smem + t * STAGE, wave, lane, t, tail_t, kvalid);
+                lb.issue_at(smem + t * STAGE + A_BYTES, wave, lane, t, tail_t, kvalid);
+            }
+        }
+        constexpr int PRE_KEEP = (NS - 1) * PT <= 63 ? NS - 1 : NS - 2;
+        const int keep = pre - 1 < PRE_KEEP ? pre - 1 : PRE_KEEP;   // tiles that may stay in flight
+        // (a compile-time immediate per case: the chain below is a few compares, executed once)
+        auto wait_keep = [&](auto self, auto c) {
+            constexpr int C = decltype(c)::value;
+            if (keep == C) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C * PT) : "memory");
+            if constexpr (C > 0) self(self, std::integral_constant<int, C - 1>{});
+        };
+        wait_keep(wait_keep, std::integral_constant<int, PRE_KEEP>{});
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -447,36 +453,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     ra.template read<0, 4>(0, fa0);
     rb.template read<0, 4>(0, fb0);
 
-    unsigned so_cur = 0, so_nxt = STAGE;   // byte offsets of the stage being computed / the next one (ring of 3)
+    unsigned so_cur = 0, so_nxt = STAGE;   // byte offsets of the stage being computed / the next one (ring of NS)
     int kt = 0;
 
-    // one K-tile: ISSUE = start the DMA of tile kt+3, NEXT = a tile kt+1 exists, KEEP = tile kt+2's DMA stays in flight
+    // one K-tile: ISSUE = start the DMA of tile kt+NS, NEXT = a tile kt+1 exists, KEEP = tiles (kt+2 ...) whose DMA stays in flight
     auto iteration = [&](auto issue_c, auto next_c, auto keep_c) {
-        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value, KEEP = decltype(keep_c)::value;
+        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+        constexpr int KEEP = decltype(keep_c)::value;
         // ---- k-step 0: set 0 has landed (reads issued one phase ago); read set 1 while the MFMAs of set 0 issue
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         ra.template read<1, 4>(so_cur, fa1);
         rb.template read<1, 4>(so_cur, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        MFMA16(fa0, fb0);
+        if (!(p.dbg & 4)) MFMA16(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- hand-over: my reads of this stage are done; everybody's DMA of tile kt+1 has landed; the DMA of tile
-        //      kt+2 (issued one iteration ago) stays in flight across the barrier: counted vmcnt, never drained
-        if constexpr (KEEP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // ---- hand-over: my reads of this stage are done; everybody's DMA of tile kt+1 has landed; the DMA of the tiles behind
+        //      it (issued in earlier iterations) stays in flight across the barrier: counted vmcnt, never drained
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP * PT) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): the two waves of a SIMD (w and w+4) would otherwise
         // run this block in lockstep - both issuing DMA/LDS reads, then both queueing on the matrix pipe.  The
         // second-dispatched half does its MFMAs first and its loads second, so one partner computes while the other loads.
-        if (wave >= NW / 2) {
+        if (wave >= NW / 2 && !(p.dbg & 4)) {
             MFMA16(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+3 into it
-            la.issue_at(smem + so_cur, wave, lane, kt + 3, tail_t, kvalid);
-            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + 3, tail_t, kvalid);
+        if (ISSUE && !(p.dbg & 8)) {      // this stage is free: start the DMA of tile kt+NS into it
+            la.issue_at(smem + so_cur, wave, lane, kt + NS, tail_t, kvalid);
+            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + NS, tail_t, kvalid);
         }
         // ---- k-step 1: read set 0 of the next tile while the MFMAs of set 1 issue
         if constexpr (NEXT) {
@@ -484,20 +490,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
             rb.template read<0, 4>(so_nxt, fb0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (wave < NW / 2) {
+        if (wave < NW / 2 && !(p.dbg & 4)) {
             MFMA16(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
         so_cur = so_nxt;
-        so_nxt = so_nxt + STAGE >= 3 * STAGE ? 0 : so_nxt + STAGE;
+        so_nxt = so_nxt + STAGE >= NS * STAGE ? 0 : so_nxt + STAGE;
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
 #pragma unroll 1
-    for (; kt + 3 < nk; ++kt) iteration(T_{}, T_{}, T_{});
-    if (kt + 2 < nk) { iteration(F_{}, T_{}, T_{}); ++kt; }
-    if (kt + 1 < nk) { iteration(F_{}, T_{}, F_{}); ++kt; }
-    iteration(F_{}, F_{}, F_{});
+    for (; kt + NS < nk; ++kt) iteration(T_{}, T_{}, std::integral_constant<int, NS - 2>{});
+    // tail: R tiles follow the current one (R = NS - 1 ... 1), R - 1 of them may stay in flight; then the last tile
+    auto tail = [&](auto self, auto r) {
+        constexpr int R = decltype(r)::value;
+        if (nk - 1 - kt == R) { iteration(F_{}, T_{}, std::integral_constant<int, R - 1>{}); ++kt; }
+        if constexpr (R > 1) self(self, std::integral_constant<int, R - 1>{});
+    };
+    tail(tail, std::integral_constant<int, NS - 1>{});
+    iteration(F_{}, F_{}, std::integral_constant<int, 0>{});
     }
     if (p.dbg & 1) return;
 
@@ -509,17 +520,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
             return;
         }
     }
-    wave_epilogue<C_F32, TM>(p, acc, smem, wave, lane, m0 + arow, n0 + bcol);
+    // (fused SwiGLU forward: a wave's 64 tile columns are 32 x columns + the 32 matching gate columns, see Loader::init)
+    wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wave, lane, m0 + arow, GLU == 1 ? tn * (BN / 2) + wn * 32 : n0 + bcol);
 }
 
-template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM>
+template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM, int GLU = 0, int NS = 3>
 int launch2(const GemmParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
-    constexpr int lds = 3 * (BM + BN) * 128;
+    constexpr int lds = NS * (BM + BN) * 128;
+    static_assert(lds <= 160 * 1024, "LDS per workgroup");
     static std::atomic<uint64_t> lds_ok{0};
-    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), lds, lds_ok);
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM, GLU, NS>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 64);
-    KALLE_LAUNCH((gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM>), grid, block, lds, st, p);
+    KALLE_LAUNCH((gemm2_kernel<A_KM, B_KM, C_F32, WM, WN, TM, GLU, NS>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
 
@@ -993,6 +1006,93 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmParams p, const fl
 }
 }  // namespace
 
+// ---- few rows, k-contiguous operands (every nn.Linear of the sampling path: M = 252 for one clip with CFG) -------------------
+// One workgroup's K loop is bound by the LDS-DMA ingest of its CU (~60 GB/s: 0.8 us per 64-deep K-tile of a 256 x 128 tile), and
+// every fp32 byte a K slice parks in a slab is paid twice (1.7 TB/s effective at this size: the write-back at the kernel's end, then
+// the finishing pass) - so instead of cutting K, the OUTPUT is cut into small tiles (64 x 64 with one wave, 128 x 64, 128 x 128) until
+// about a workgroup per CU exists, each over the whole K with the full epilogue in the same launch; only K > 2048 is also cut
+// into slices (slabs + finishing pass).  `cfg` packs the choice for kalle_gemm_last_plan: 5 | WM << 8 | WN << 12 | splits << 16.
+template <bool C_F32, int GLU>
+int launch_skinny_tile(int wm, int wn, const GemmParams& q, hipStream_t st) {
+    // ring depth: a lone workgroup per CU has nobody to cover its DMA latency (~1 us) - the ring does: 4 tiles ahead
+    if (wm == 1 && wn == 1) return launch2<false, false, C_F32, 1, 1, 4, GLU, 5>(q, st);       // 80 KiB
+    if (wm == 2 && wn == 1) return launch2<false, false, C_F32, 2, 1, 4, GLU, 5>(q, st);       // 120 KiB
+    if (wm == 2 && wn == 2) return launch2<false, false, C_F32, 2, 2, 4, GLU, 4>(q, st);       // 128 KiB
+    return KALLE_ERR_UNSUPPORTED;
+}
+
+int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f32, void* ws, int64_t ws_bytes, hipStream_t st,
+                             int* cfg) {
+    static const char* env = getenv("KALLE_SKINNY");           // "0": off; "wm,wn,splits": forced configuration (experiments)
+    if (env && env[0] == '0' && !env[1]) return KALLE_ERR_UNSUPPORTED;
+    if (a_km || b_km || pin.M > 512 || (pin.K & 7) || (pin.N & 63) || pin.atomic) return KALLE_ERR_UNSUPPORTED;
+    if (pin.glu_mode == 2 || (pin.glu_mode == 1 && (f32 || pin.N != 2 * pin.glu_inner || (pin.glu_inner & 31) || pin.gate ||
+                                                    pin.residual || pin.row_mask || pin.c_rpb || pin.accumulate)))
+        return KALLE_ERR_UNSUPPORTED;
+    const int nk = (pin.K + BK2 - 1) / BK2;
+    const int ncol = pin.glu_mode == 1 ? pin.glu_inner * 2 : pin.N;
+    // candidate tiles, smallest first; cost (us) = K-tiles per workgroup x the ingest time of the tiles sharing a CU + slab traffic
+    static const int cand[3][2] = {{1, 1}, {2, 1}, {2, 2}};
+    int wm = 0, wn = 0, splits = 1;
+    double best = 1e30;
+    int fwm = 0, fwn = 0, fs = 0;
+    const bool forced = env && sscanf(env, "%d,%d,%d", &fwm, &fwn, &fs) == 3;
+    for (int c = 0; c < 3; ++c) {
+        const int bm = cand[c][0] * 64, bn = cand[c][1] * 64;
+        if (pin.glu_mode == 1 && (pin.glu_inner % (bn / 2))) continue;
+        const int tiles = ((pin.M + bm - 1) / bm) * ((ncol + bn - 1) / bn);
+        for (int sp = 1; sp <= 8; ++sp) {
+            if (sp > 1 && (nk / sp < 12 || !ws || pin.glu_mode)) break;
+            if (sp > 1 && (int64_t)sp * pin.M * pin.N * 4 > ws_bytes) break;
+            const double wgs = (double)tiles * sp;
+            const double per_cu = wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0;           // workgroups sharing a CU's ingest path
+            const double tk = (bm + bn) * 128.0 / 60e3 * per_cu;                   // us per K-tile
+            const double tk_floor = 0.22 * per_cu;                                 // a lone wave's read -> MFMA chain
+            double t = 4.0 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor);
+            if (sp > 1) t += 4.0 + 2.0 * sp * pin.M * (double)pin.N * 4.0 / 1.7e6;  // slabs: second launch + write + read back
+            const bool pick = forced ? (cand[c][0] == fwm && cand[c][1] == fwn && sp == fs) : t < best;
+            if (pick) { best = t; wm = cand[c][0]; wn = cand[c][1]; splits = sp; }
+        }
+    }
+    if (!wm) return KALLE_ERR_UNSUPPORTED;
+    const int bm = wm * 64, bn = wn * 64;
+    GemmParams q = pin;
+    q.tiles_m = (pin.M + bm - 1) / bm;
+    q.tiles_n = (ncol + bn - 1) / bn;
+    q.tile_n = bn;
+    q.group_m = q.tiles_m < 4 ? q.tiles_m : 4;
+    q.atomic = 0;
+    q.mix_na = -1;
+    q.ktiles_per_split = (nk + splits - 1) / splits;
+    q.splits = (nk + q.ktiles_per_split - 1) / q.ktiles_per_split;
+    q.slab_stride = 0;
+    static const int dbg = getenv("KALLE_FEW_ROWS_DBG") ? atoi(getenv("KALLE_FEW_ROWS_DBG")) : 0;
+    q.dbg = dbg;
+    if (cfg) *cfg = 5 | (wm << 8) | (wn << 12) | (q.splits << 16);
+    if (q.splits == 1) {
+        if (pin.glu_mode == 1) return launch_skinny_tile<false, 1>(wm, wn, q, st);
+        return f32 ? launch_skinny_tile<true, 0>(wm, wn, q, st) : launch_skinny_tile<false, 0>(wm, wn, q, st);
+    }
+    // K slices into fp32 slabs (plain epilogue-free stores), then the finishing pass with the caller's epilogue
+    GemmParams sl{};
+    sl.A = pin.A; sl.B = pin.B; sl.C = ws;
+    sl.lda = pin.lda; sl.ldb = pin.ldb; sl.ldc = pin.N;
+    sl.M = pin.M; sl.N = pin.N; sl.K = pin.K;
+    sl.alpha = 1.f;
+    sl.rows_per_batch = 1;
+    sl.tiles_m = q.tiles_m; sl.tiles_n = q.tiles_n; sl.tile_n = bn; sl.group_m = q.group_m;
+    sl.mix_na = -1;
+    sl.ktiles_per_split = q.ktiles_per_split; sl.splits = q.splits;
+    sl.slab_stride = (int64_t)pin.M * pin.N;
+    const int rc = launch_skinny_tile<true, 0>(wm, wn, sl, st);
+    if (rc != KALLE_OK) return rc;
+    const int64_t work = (int64_t)pin.M * (pin.N >> 2);
+    const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    if (f32) KALLE_LAUNCH(gemm_finish_kernel<true>, dim3(grid), dim3(256), 0, st, pin, static_cast<const float*>(ws), q.splits);
+    else KALLE_LAUNCH(gemm_finish_kernel<false>, dim3(grid), dim3(256), 0, st, pin, static_cast<const float*>(ws), q.splits);
+    return kalle_check_launch();
+}
+
 // returns KALLE_ERR_UNSUPPORTED when the shape is better served by the ordinary path (the caller goes on to it)
 int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool f32, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (a_km || !ws || pin.M > 4096 || (pin.K & 7) || (pin.N & 7)) return KALLE_ERR_UNSUPPORTED;
@@ -1076,6 +1176,15 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool f32 = c_dtype == KALLE_F32;
+    if (force_mode() != 1) {
+        int cfg = 0;
+        const int rc = kalle_gemm_skinny_launch(p, a_kmajor != 0, b_kmajor != 0, f32, ep ? ep->workspace : nullptr,
+                                                ep ? ep->workspace_bytes : 0, st, &cfg);
+        if (rc != KALLE_ERR_UNSUPPORTED) {
+            g_last_plan = cfg;
+            return rc;
+        }
+    }
     if (ep && ep->workspace && force_mode() != 1) {
         const int rc = kalle_gemm_few_rows_launch(p, a_kmajor != 0, b_kmajor != 0, f32, ep->workspace, ep->workspace_bytes, st);
         if (rc != KALLE_ERR_UNSUPPORTED) {
