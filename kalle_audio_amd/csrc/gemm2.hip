@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
 
-    if (!(p.dbg & 2)) {      // (debug knob: bit 1 skips the pipeline, bit 0 the stores - tools/skinny_knockout.sh)
+    {
     // prologue: up to NS tiles in flight (ring of NS stages); wait for tile 0 (for tile 1 too where the 6-bit vmcnt could not
     // name NS - 1 tiles)
     constexpr int PT = Loader<A_KM, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;   // DMA pieces per tile per wave
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
         ra.template read<1, 4>(so_cur, fa1);
         rb.template read<1, 4>(so_cur, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(p.dbg & 4)) MFMA16(fa0, fb0);
+        MFMA16(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hand-over: my reads of this stage are done; everybody's DMA of tile kt+1 has landed; the DMA of the tiles behind
         //      it (issued in earlier iterations) stays in flight across the barrier: counted vmcnt, never drained
@@ -476,11 +476,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
         // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): the two waves of a SIMD (w and w+4) would otherwise
         // run this block in lockstep - both issuing DMA/LDS reads, then both queueing on the matrix pipe.  The
         // second-dispatched half does its MFMAs first and its loads second, so one partner computes while the other loads.
-        if (wave >= NW / 2 && !(p.dbg & 4)) {
+        if (wave >= NW / 2) {
             MFMA16(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (ISSUE && !(p.dbg & 8)) {      // this stage is free: start the DMA of tile kt+NS into it
+        if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+NS into it
             la.issue_at(smem + so_cur, wave, lane, kt + NS, tail_t, kvalid);
             lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + NS, tail_t, kvalid);
         }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
             rb.template read<0, 4>(so_nxt, fb0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (wave < NW / 2 && !(p.dbg & 4)) {
+        if (wave < NW / 2) {
             MFMA16(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -510,7 +510,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     tail(tail, std::integral_constant<int, NS - 1>{});
     iteration(F_{}, F_{}, std::integral_constant<int, 0>{});
     }
-    if (p.dbg & 1) return;
 
     if constexpr (C_F32) {
         if (p.slab_stride) {        // split-K into per-slice slabs (few-rows path)
@@ -522,6 +521,172 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
     }
     // (fused SwiGLU forward: a wave's 64 tile columns are 32 x columns + the 32 matching gate columns, see Loader::init)
     wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wave, lane, m0 + arow, GLU == 1 ? tn * (BN / 2) + wn * 32 : n0 + bcol);
+}
+
+
+// ---- the same tile with TWO wave groups (few-row GEMMs: one workgroup per CU at best, so nobody covers a wave's LDS / DMA-issue
+// latency but its own SIMD partner): group 0 multiplies the first 32-deep k-step of every stage, group 1 the second - two waves per
+// SIMD on the same 64 x 64 sub-tile, 16 MFMAs per wave per K-tile, the DMA pieces spread over twice the waves; group 1's partial
+// sums travel through LDS to group 0 before the epilogue.  Sum order per output: (k-step 0 of every tile) + (k-step 1 of every
+// tile) - fixed, so results are reproducible, but not bit-identical to the one-group kernel.
+template <bool C_F32, int WM, int WN, int GLU, int NS>
+__global__ __launch_bounds__(WM * WN * 128, 1) void gemm2_ks2_kernel(GemmParams p) {
+    constexpr int TM = 4, TN = 4;
+    constexpr int NWT = WM * WN, NW = 2 * NWT;
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int RED_OFF = 32768;                                   // behind the epilogue's wave patches
+    static_assert(RED_OFF + NWT * 16384 <= NS * STAGE, "partial-sum exchange must fit into the ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(char, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / NWT, wt = wave % NWT;
+    const int wm = wt / WN, wn = wt % WN;
+
+    int tm, tn;
+    gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk_all = (p.K + BK2 - 1) / BK2;
+    const int kt0 = blockIdx.y * p.ktiles_per_split;
+    const int nk = min(p.ktiles_per_split, nk_all - kt0);
+    const int kvalid = p.K % BK2;
+    const int tail_t = kvalid ? nk_all - 1 - kt0 : -1;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Loader<false, BM, NW> la;
+    Loader<false, BN, NW> lb;
+    la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
+    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
+    const int arow = wm * 64, bcol = wn * 64;
+    Reader<false, BM> ra;
+    Reader<false, BN> rb;
+    ra.init(lds0, arow, lane);
+    rb.init(lds0 + A_BYTES, bcol, lane);
+
+    constexpr int PT = Loader<false, BM, NW>::PER_WAVE + Loader<false, BN, NW>::PER_WAVE;
+    static_assert((NS - 1) * PT <= 63, "vmcnt is a 6-bit counter");
+    {
+        const int pre = nk < NS ? nk : NS;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (t < pre) {
+                la.issue_at(smem + t * STAGE, wave, lane, t, tail_t, kvalid);
+                lb.issue_at(smem + t * STAGE + A_BYTES, wave, lane, t, tail_t, kvalid);
+            }
+        }
+        const int keep = pre - 1;
+        auto wait_keep = [&](auto self, auto c) {
+            constexpr int C = decltype(c)::value;
+            if (keep == C) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C * PT) : "memory");
+            if constexpr (C > 0) self(self, std::integral_constant<int, C - 1>{});
+        };
+        wait_keep(wait_keep, std::integral_constant<int, NS - 1>{});
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    i32x4 fa[2][4], fb[2][4];            // my k-step's fragments of the tile being multiplied / of the next one
+    auto rd = [&](unsigned so, i32x4 (&A)[4], i32x4 (&B)[4]) {
+        if (kg == 0) { ra.template read<0, 4>(so, A); rb.template read<0, 4>(so, B); }
+        else { ra.template read<1, 4>(so, A); rb.template read<1, 4>(so, B); }
+    };
+    rd(0, fa[0], fb[0]);
+    unsigned so_cur = 0, so_nxt = STAGE;
+    int kt = 0;
+
+    // one K-tile; P = which fragment buffer holds it; KEEP = tiles (kt+2 ...) whose DMA may stay in flight at the hand-over
+    auto iteration = [&](auto par_c, auto issue_c, auto next_c, auto keep_c) {
+        constexpr int P = decltype(par_c)::value, KEEP = decltype(keep_c)::value;
+        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+        // my fragments of tile kt are in registers (so stage kt may be refilled once everybody says the same) and my pieces of
+        // tile kt+1 have landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP * PT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT) rd(so_nxt, fa[1 - P], fb[1 - P]);
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA16(fa[P], fb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ISSUE) {
+            la.issue_at(smem + so_cur, wave, lane, kt + NS, tail_t, kvalid);
+            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + NS, tail_t, kvalid);
+        }
+        so_cur = so_nxt;
+        so_nxt = so_nxt + STAGE >= NS * STAGE ? 0 : so_nxt + STAGE;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using KS_ = std::integral_constant<int, NS - 2>;
+#pragma unroll 1
+    for (; kt + NS + 1 < nk; kt += 2) {
+        iteration(P0{}, T_{}, T_{}, KS_{});
+        ++kt; iteration(P1{}, T_{}, T_{}, KS_{}); --kt;
+    }
+    int par = 0;
+    if (kt + NS < nk) { iteration(P0{}, T_{}, T_{}, KS_{}); ++kt; par = 1; }
+    auto tail = [&](auto self, auto r) {
+        constexpr int R = decltype(r)::value;
+        if (nk - 1 - kt == R) {
+            if (par) iteration(P1{}, F_{}, T_{}, std::integral_constant<int, R - 1>{});
+            else iteration(P0{}, F_{}, T_{}, std::integral_constant<int, R - 1>{});
+            ++kt; par ^= 1;
+        }
+        if constexpr (R > 1) self(self, std::integral_constant<int, R - 1>{});
+    };
+    tail(tail, std::integral_constant<int, NS - 1>{});
+    if (par) iteration(P1{}, F_{}, F_{}, P0{});
+    else iteration(P0{}, F_{}, F_{}, P0{});
+
+    // ---- group 1 hands its partial sums to group 0 (register layout kept: 16 bytes per lane per accumulator, conflict-free)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = reinterpret_cast<float*>(smem + RED_OFF) + wt * 4096;
+    if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(red + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kg == 1) {
+        __builtin_amdgcn_s_barrier();       // (the barrier at the top of wave_epilogue, which group 0 is entering)
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(red + ((i * TN + j) * 64 + lane) * 4);
+    if constexpr (C_F32) {
+        if (p.slab_stride) {
+            GemmParams q = p;
+            q.C = static_cast<float*>(p.C) + (int64_t)blockIdx.y * p.slab_stride;
+            wave_epilogue<C_F32, TM>(q, acc, smem, wt, lane, m0 + arow, n0 + bcol);
+            return;
+        }
+    }
+    wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wt, lane, m0 + arow, GLU == 1 ? tn * (BN / 2) + wn * 32 : n0 + bcol);
+}
+
+template <bool C_F32, int WM, int WN, int GLU, int NS>
+int launch2_ks2(const GemmParams& p, hipStream_t st) {
+    constexpr int lds = NS * (WM + WN) * 64 * 128;
+    static_assert(lds <= 160 * 1024, "LDS per workgroup");
+    static std::atomic<uint64_t> lds_ok{0};
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_ks2_kernel<C_F32, WM, WN, GLU, NS>), lds, lds_ok);
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 128);
+    KALLE_LAUNCH((gemm2_ks2_kernel<C_F32, WM, WN, GLU, NS>), grid, block, lds, st, p);
+    return kalle_check_launch();
 }
 
 template <bool A_KM, bool B_KM, bool C_F32, int WM, int WN, int TM, int GLU = 0, int NS = 3>
@@ -1014,10 +1179,15 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmParams p, const fl
 // into slices (slabs + finishing pass).  `cfg` packs the choice for kalle_gemm_last_plan: 5 | WM << 8 | WN << 12 | splits << 16.
 template <bool C_F32, int GLU>
 int launch_skinny_tile(int wm, int wn, const GemmParams& q, hipStream_t st) {
-    // ring depth: a lone workgroup per CU has nobody to cover its DMA latency (~1 us) - the ring does: 4 tiles ahead
-    if (wm == 1 && wn == 1) return launch2<false, false, C_F32, 1, 1, 4, GLU, 5>(q, st);       // 80 KiB
-    if (wm == 2 && wn == 1) return launch2<false, false, C_F32, 2, 1, 4, GLU, 5>(q, st);       // 120 KiB
-    if (wm == 2 && wn == 2) return launch2<false, false, C_F32, 2, 2, 4, GLU, 4>(q, st);       // 128 KiB
+    static const bool one_group = getenv("KALLE_SKINNY_KS") && atoi(getenv("KALLE_SKINNY_KS")) == 1;    // experiment switch
+    if (!one_group) {       // two wave groups per tile (one per 32-deep k-step): two waves per SIMD cover each other
+        if (wm == 1 && wn == 1) return launch2_ks2<C_F32, 1, 1, GLU, 5>(q, st);                // 80 KiB
+        if (wm == 2 && wn == 1) return launch2_ks2<C_F32, 2, 1, GLU, 5>(q, st);                // 120 KiB
+        if (wm == 2 && wn == 2) return launch2_ks2<C_F32, 2, 2, GLU, 4>(q, st);                // 128 KiB
+    }
+    if (wm == 1 && wn == 1) return launch2<false, false, C_F32, 1, 1, 4, GLU, 5>(q, st);
+    if (wm == 2 && wn == 1) return launch2<false, false, C_F32, 2, 1, 4, GLU, 5>(q, st);
+    if (wm == 2 && wn == 2) return launch2<false, false, C_F32, 2, 2, 4, GLU, 4>(q, st);
     return KALLE_ERR_UNSUPPORTED;
 }
 
@@ -1047,8 +1217,8 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
             const double wgs = (double)tiles * sp;
             const double per_cu = wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0;           // workgroups sharing a CU's ingest path
             const double tk = (bm + bn) * 128.0 / 60e3 * per_cu;                   // us per K-tile
-            const double tk_floor = 0.22 * per_cu;                                 // a lone wave's read -> MFMA chain
-            double t = 4.0 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor);
+            const double tk_floor = 0.30 * per_cu;                                 // barrier + fragment reads + 16 MFMAs per wave
+            double t = 5.5 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor);
             if (sp > 1) t += 4.0 + 2.0 * sp * pin.M * (double)pin.N * 4.0 / 1.7e6;  // slabs: second launch + write + read back
             const bool pick = forced ? (cand[c][0] == fwm && cand[c][1] == fwn && sp == fs) : t < best;
             if (pick) { best = t; wm = cand[c][0]; wn = cand[c][1]; splits = sp; }
@@ -1066,8 +1236,6 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
     q.ktiles_per_split = (nk + splits - 1) / splits;
     q.splits = (nk + q.ktiles_per_split - 1) / q.ktiles_per_split;
     q.slab_stride = 0;
-    static const int dbg = getenv("KALLE_FEW_ROWS_DBG") ? atoi(getenv("KALLE_FEW_ROWS_DBG")) : 0;
-    q.dbg = dbg;
     if (cfg) *cfg = 5 | (wm << 8) | (wn << 12) | (q.splits << 16);
     if (q.splits == 1) {
         if (pin.glu_mode == 1) return launch_skinny_tile<false, 1>(wm, wn, q, st);
@@ -1126,8 +1294,6 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     q.ktiles_per_split = (nk + splits - 1) / splits;
     q.splits = (nk + q.ktiles_per_split - 1) / q.ktiles_per_split;
     q.slab_stride = slab;
-    static const int dbg = getenv("KALLE_FEW_ROWS_DBG") ? atoi(getenv("KALLE_FEW_ROWS_DBG")) : 0;
-    q.dbg = dbg;
     const int rc = b_km ? launch2<false, true, true, 4, 2, 4>(q, st) : launch2<false, false, true, 4, 2, 4>(q, st);
     if (rc != KALLE_OK) return rc;
     GemmParams f = pin;

@@ -33,7 +33,6 @@ struct GemmParams {
     // few-rows split-K (gemm2 only): K slice s stores its partial tile to C + s * slab_stride (plain stores, summed in a fixed
     // order by the finishing pass: deterministic, and plain stores run ~4x the rate of float atomics); 0: off
     int64_t slab_stride;
-    int dbg;                // timing experiments only (KALLE_FEW_ROWS_DBG): bit 0 no stores, bit 1 no pipeline
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a
