@@ -37,11 +37,22 @@ def f32_of(p):
     return d if d.dtype == F32 else d.float()
 
 
-def rope_tables(freqs):
-    """freqs: [N, rot] as produced by RotaryEmbedding (cat(f, f)); returns cos/sin [N, rot/2] fp32 for the kernel."""
+def rope_tables(freqs, n=None):
+    """freqs: [N, rot] as produced by RotaryEmbedding (cat(f, f)); returns cos/sin [n, rot/2] fp32 (last n positions) for the
+    kernel.  The tables ride on the freqs tensor: ContinuousTransformer hands the same tensor to all of its layers, so the two
+    trigonometric passes run once per forward instead of once per layer."""
+    n = freqs.shape[0] if n is None else n
+    hit = getattr(freqs, "_kalle_rope", None)
+    if hit is not None and hit[0] == (n, freqs._version):
+        return hit[1]
     half = freqs.shape[-1] // 2
-    f = freqs[:, :half].float()
-    return f.cos().contiguous(), f.sin().contiguous()
+    f = freqs[-n:, :half].float()
+    tab = (f.cos().contiguous(), f.sin().contiguous())
+    try:
+        freqs._kalle_rope = ((n, freqs._version), tab)
+    except (AttributeError, RuntimeError):
+        pass
+    return tab
 
 
 class GradOut:

@@ -371,7 +371,7 @@ def transformer_block(blk, x, context=None, global_cond=None, mask=None, context
     rope = None
     if rotary_pos_emb is not None:
         freqs = rotary_pos_emb[0] if isinstance(rotary_pos_emb, (tuple, list)) else rotary_pos_emb
-        rope = D.rope_tables(freqs[-x.shape[1]:])
+        rope = D.rope_tables(freqs, x.shape[1])
     return TransformerBlockFn.apply(blk, x, context, global_cond, _mask8(mask), _mask8(context_mask), rope,
                                     *[have[n] for n in names])
 

@@ -141,7 +141,7 @@ class Attention(nn.Module):
         rope = None
         if rotary_pos_emb is not None and context is None:
             freqs = rotary_pos_emb[0] if isinstance(rotary_pos_emb, (tuple, list)) else rotary_pos_emb
-            rope = KF.D.rope_tables(freqs[-x.shape[1]:])
+            rope = KF.D.rope_tables(freqs, x.shape[1])
         if hasattr(self, "to_q"):
             params = (self.to_q.weight, self.to_kv.weight, self.to_out.weight)
         else:
