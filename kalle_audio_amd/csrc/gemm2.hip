@@ -529,8 +529,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmParams p) {
 // SIMD on the same 64 x 64 sub-tile, 16 MFMAs per wave per K-tile, the DMA pieces spread over twice the waves; group 1's partial
 // sums travel through LDS to group 0 before the epilogue.  Sum order per output: (k-step 0 of every tile) + (k-step 1 of every
 // tile) - fixed, so results are reproducible, but not bit-identical to the one-group kernel.
-template <bool C_F32, int WM, int WN, int GLU, int NS>
+template <bool B_KM, bool C_F32, int WM, int WN, int GLU, int NS>
 __global__ __launch_bounds__(WM * WN * 128, 1) void gemm2_ks2_kernel(GemmParams p) {
+    static_assert(!B_KM || WN >= 2, "a k-major operand tile needs >= 128 columns (16 swizzle slots per k-row)");
     constexpr int TM = 4, TN = 4;
     constexpr int NWT = WM * WN, NW = 2 * NWT;
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -562,16 +563,16 @@ __global__ __launch_bounds__(WM * WN * 128, 1) void gemm2_ks2_kernel(GemmParams 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Loader<false, BM, NW> la;
-    Loader<false, BN, NW> lb;
+    Loader<B_KM, BN, NW> lb;
     la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
     lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
     const int arow = wm * 64, bcol = wn * 64;
     Reader<false, BM> ra;
-    Reader<false, BN> rb;
+    Reader<B_KM, BN> rb;
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
 
-    constexpr int PT = Loader<false, BM, NW>::PER_WAVE + Loader<false, BN, NW>::PER_WAVE;
+    constexpr int PT = Loader<false, BM, NW>::PER_WAVE + Loader<B_KM, BN, NW>::PER_WAVE;
     static_assert((NS - 1) * PT <= 63, "vmcnt is a 6-bit counter");
     {
         const int pre = nk < NS ? nk : NS;
@@ -678,14 +679,14 @@ __global__ __launch_bounds__(WM * WN * 128, 1) void gemm2_ks2_kernel(GemmParams 
     wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wt, lane, m0 + arow, GLU == 1 ? tn * (BN / 2) + wn * 32 : n0 + bcol);
 }
 
-template <bool C_F32, int WM, int WN, int GLU, int NS>
+template <bool B_KM, bool C_F32, int WM, int WN, int GLU, int NS>
 int launch2_ks2(const GemmParams& p, hipStream_t st) {
     constexpr int lds = NS * (WM + WN) * 64 * 128;
     static_assert(lds <= 160 * 1024, "LDS per workgroup");
     static std::atomic<uint64_t> lds_ok{0};
-    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_ks2_kernel<C_F32, WM, WN, GLU, NS>), lds, lds_ok);
+    kalle_allow_lds(reinterpret_cast<const void*>(gemm2_ks2_kernel<B_KM, C_F32, WM, WN, GLU, NS>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(WM * WN * 128);
-    KALLE_LAUNCH((gemm2_ks2_kernel<C_F32, WM, WN, GLU, NS>), grid, block, lds, st, p);
+    KALLE_LAUNCH((gemm2_ks2_kernel<B_KM, C_F32, WM, WN, GLU, NS>), grid, block, lds, st, p);
     return kalle_check_launch();
 }
 
@@ -1178,12 +1179,18 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmParams p, const fl
 // about a workgroup per CU exists, each over the whole K with the full epilogue in the same launch; only K > 2048 is also cut
 // into slices (slabs + finishing pass).  `cfg` packs the choice for kalle_gemm_last_plan: 5 | WM << 8 | WN << 12 | splits << 16.
 template <bool C_F32, int GLU>
-int launch_skinny_tile(int wm, int wn, const GemmParams& q, hipStream_t st) {
+int launch_skinny_tile(int wm, int wn, const GemmParams& q, hipStream_t st, bool b_km = false) {
     static const bool one_group = getenv("KALLE_SKINNY_KS") && atoi(getenv("KALLE_SKINNY_KS")) == 1;    // experiment switch
+    if (b_km) {             // k-major weights (data gradients): 128-column tiles only
+        if constexpr (GLU == 0) {
+            if (wm == 2 && wn == 2) return launch2_ks2<true, C_F32, 2, 2, 0, 4>(q, st);
+        }
+        return KALLE_ERR_UNSUPPORTED;
+    }
     if (!one_group) {       // two wave groups per tile (one per 32-deep k-step): two waves per SIMD cover each other
-        if (wm == 1 && wn == 1) return launch2_ks2<C_F32, 1, 1, GLU, 5>(q, st);                // 80 KiB
-        if (wm == 2 && wn == 1) return launch2_ks2<C_F32, 2, 1, GLU, 5>(q, st);                // 120 KiB
-        if (wm == 2 && wn == 2) return launch2_ks2<C_F32, 2, 2, GLU, 4>(q, st);                // 128 KiB
+        if (wm == 1 && wn == 1) return launch2_ks2<false, C_F32, 1, 1, GLU, 5>(q, st);         // 80 KiB
+        if (wm == 2 && wn == 1) return launch2_ks2<false, C_F32, 2, 1, GLU, 5>(q, st);         // 120 KiB
+        if (wm == 2 && wn == 2) return launch2_ks2<false, C_F32, 2, 2, GLU, 4>(q, st);         // 128 KiB
     }
     if (wm == 1 && wn == 1) return launch2<false, false, C_F32, 1, 1, 4, GLU, 5>(q, st);
     if (wm == 2 && wn == 1) return launch2<false, false, C_F32, 2, 1, 4, GLU, 5>(q, st);
@@ -1195,10 +1202,14 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
                              int* cfg) {
     static const char* env = getenv("KALLE_SKINNY");           // "0": off; "wm,wn,splits": forced configuration (experiments)
     if (env && env[0] == '0' && !env[1]) return KALLE_ERR_UNSUPPORTED;
-    if (a_km || b_km || pin.M > 512 || (pin.K & 7) || (pin.N & 63) || pin.atomic) return KALLE_ERR_UNSUPPORTED;
+    static const int max_m = getenv("KALLE_SKINNY_MAX_M") ? atoi(getenv("KALLE_SKINNY_MAX_M")) : 2048;
+    if (a_km || pin.M > max_m || (pin.K & 7) || (pin.N & 63) || pin.atomic) return KALLE_ERR_UNSUPPORTED;
+    if (b_km && ((pin.N & 127) || pin.glu_mode)) return KALLE_ERR_UNSUPPORTED;
     if (pin.glu_mode == 2 || (pin.glu_mode == 1 && (f32 || pin.N != 2 * pin.glu_inner || (pin.glu_inner & 31) || pin.gate ||
                                                     pin.residual || pin.row_mask || pin.c_rpb || pin.accumulate)))
         return KALLE_ERR_UNSUPPORTED;
+    // outputs with a chip's worth of 256 x 256 tiles belong to the big-tile kernels (twice the flops per ingested byte)
+    if ((int64_t)((pin.M + 255) / 256) * ((pin.N + 255) / 256) >= 256) return KALLE_ERR_UNSUPPORTED;
     const int nk = (pin.K + BK2 - 1) / BK2;
     const int ncol = pin.glu_mode == 1 ? pin.glu_inner * 2 : pin.N;
     // candidate tiles, smallest first; cost (us) = K-tiles per workgroup x the ingest time of the tiles sharing a CU + slab traffic
@@ -1210,15 +1221,20 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
     for (int c = 0; c < 3; ++c) {
         const int bm = cand[c][0] * 64, bn = cand[c][1] * 64;
         if (pin.glu_mode == 1 && (pin.glu_inner % (bn / 2))) continue;
+        if (b_km && bn < 128) continue;
         const int tiles = ((pin.M + bm - 1) / bm) * ((ncol + bn - 1) / bn);
         for (int sp = 1; sp <= 8; ++sp) {
             if (sp > 1 && (nk / sp < 12 || !ws || pin.glu_mode)) break;
             if (sp > 1 && (int64_t)sp * pin.M * pin.N * 4 > ws_bytes) break;
+            // more than a few tile rows (training at small batch): measured against the 256-row kernels, the small tiles win only
+            // while they fit one round of workgroups and K is moderate (B = 16: 2016 x 1536 x 1536 30 -> 25 us, x 4608 64 -> 50,
+            // x 6144 78 -> 65; but 2016 x 4608 x 1536 in 2.25 rounds 57 -> 65 and K = 12288 115 -> 122)
+            if (pin.M > 512 && (tiles * sp > 256 || nk > 128)) continue;
             const double wgs = (double)tiles * sp;
-            const double per_cu = wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0;           // workgroups sharing a CU's ingest path
-            const double tk = (bm + bn) * 128.0 / 60e3 * per_cu;                   // us per K-tile
-            const double tk_floor = 0.30 * per_cu;                                 // barrier + fragment reads + 16 MFMAs per wave
-            double t = 5.5 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor);
+            const double rounds = wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0;           // one workgroup per CU at a time (80-128 KiB of LDS)
+            const double tk = (bm + bn) * 128.0 / 60e3;                            // us per K-tile: the CU's LDS-DMA ingest ...
+            const double tk_floor = 0.30;                                          // ... or barrier + fragment reads + 16 MFMAs per wave
+            double t = 2.5 + rounds * (3.0 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor));
             if (sp > 1) t += 4.0 + 2.0 * sp * pin.M * (double)pin.N * 4.0 / 1.7e6;  // slabs: second launch + write + read back
             const bool pick = forced ? (cand[c][0] == fwm && cand[c][1] == fwn && sp == fs) : t < best;
             if (pick) { best = t; wm = cand[c][0]; wn = cand[c][1]; splits = sp; }
@@ -1239,7 +1255,7 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
     if (cfg) *cfg = 5 | (wm << 8) | (wn << 12) | (q.splits << 16);
     if (q.splits == 1) {
         if (pin.glu_mode == 1) return launch_skinny_tile<false, 1>(wm, wn, q, st);
-        return f32 ? launch_skinny_tile<true, 0>(wm, wn, q, st) : launch_skinny_tile<false, 0>(wm, wn, q, st);
+        return f32 ? launch_skinny_tile<true, 0>(wm, wn, q, st, b_km) : launch_skinny_tile<false, 0>(wm, wn, q, st, b_km);
     }
     // K slices into fp32 slabs (plain epilogue-free stores), then the finishing pass with the caller's epilogue
     GemmParams sl{};
@@ -1252,7 +1268,7 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
     sl.mix_na = -1;
     sl.ktiles_per_split = q.ktiles_per_split; sl.splits = q.splits;
     sl.slab_stride = (int64_t)pin.M * pin.N;
-    const int rc = launch_skinny_tile<true, 0>(wm, wn, sl, st);
+    const int rc = launch_skinny_tile<true, 0>(wm, wn, sl, st, b_km);
     if (rc != KALLE_OK) return rc;
     const int64_t work = (int64_t)pin.M * (pin.N >> 2);
     const int grid = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);

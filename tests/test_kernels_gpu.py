@@ -103,7 +103,7 @@ def test_gemm_fused_swiglu_matches_unfused(ops, dev):
 
 
 def _fused_swiglu_body(ops, dev):
-    M, D, inner = 640, 256, 512
+    M, D, inner = 2304, 256, 512          # (more rows than the small-tile path takes: both sides run the 256-row kernels)
     x = _mk((M, D), dev, seed=80).bfloat16()
     w1 = (_mk((2 * inner, D), dev, seed=81) * 0.1).bfloat16()
     b1 = _mk((2 * inner,), dev, seed=82) * 0.1
@@ -122,7 +122,10 @@ def _fused_swiglu_body(ops, dev):
     db = torch.zeros(2 * inner, device=dev)
     assert ops.gemm(gb, w2, b_kmajor=True, out=dh, N=inner, glu_mode=2, glu_inner=inner, glu_aux=h_ref,
                     glu_dbias=db) is not None
-    assert torch.equal(dh, dh_ref)
+    # the activation backward is compiled twice (GEMM epilogue / stand-alone kernel, both -ffast-math): the same formula may round
+    # a sigmoid differently by one ulp - a handful of the 2.4 M outputs differ by one bf16 step, everything else bit for bit
+    ne = dh != dh_ref
+    assert int(ne.sum()) <= 32 and rel_l2(dh.float(), dh_ref.float()) < 1e-4, (int(ne.sum()), rel_l2(dh.float(), dh_ref.float()))
     assert rel_l2(db, db_ref) < 1e-5
     # few rows (<= 512): the small-tile kernels carry the same fused epilogue (64 / 128-column tiles, 32 x + 32 gate columns per wave)
     # (bit for bit against the same kernel family without the fused epilogue; against the 256-row kernels the sum order differs)

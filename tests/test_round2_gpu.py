@@ -898,13 +898,15 @@ def test_training_step_with_enable_grad_pretransform(dev, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ few-rows GEMM path
-@pytest.mark.parametrize("M,N,K", [(252, 1536, 1536), (252, 4608, 1536), (126, 1536, 6144), (504, 1536, 12288), (504, 768, 200)])
+@pytest.mark.parametrize("M,N,K", [(252, 1536, 1536), (252, 4608, 1536), (126, 1536, 6144), (504, 1536, 12288), (504, 768, 200),
+                                   (2016, 1536, 1536), (2520, 1536, 6144), (252, 1472, 1536)])
 @pytest.mark.parametrize("b_km", [False, True])
 def test_gemm_few_rows_splitk_path(dev, M, N, K, b_km):
     """M <= 4096 rows (sampling at generation batch sizes, B = 16 training).  k-major weights (data gradients): K is cut into
-    slices that write fp32 slabs into the caller's scratch, a finishing pass sums them in order and applies the epilogue (plan 4).
-    k-contiguous operands with M <= 512 (every nn.Linear of the sampling path): small output tiles (64 x 64 ... 128 x 128, two
-    wave groups per tile) over the whole K with the epilogue in the same launch, K slices + slabs only for long K (plan 5).
+    slices that write fp32 slabs into the caller's scratch, a finishing pass sums them in order and applies the epilogue (plan 4:
+    2048 < M <= 4096, or column counts the small tiles do not take).  M <= 2048 (every nn.Linear of the sampling path, B = 16
+    training): small output tiles (64 x 64 ... 128 x 128, two wave groups per tile; k-major weights 128 x 128) over the whole K
+    with the epilogue in the same launch, K slices + slabs only for long K (plan 5).
     Same numbers as the ordinary path (fp32 accumulation of the same bf16 products), every epilogue option, and bitwise
     identical from run to run."""
     from kalle_audio_amd import ops, _lib
@@ -922,7 +924,7 @@ def test_gemm_few_rows_splitk_path(dev, M, N, K, b_km):
         return out, lib.kalle_gemm_last_plan() & 255
 
     y, plan = run(out_dtype=torch.float32)
-    want = 5 if (not b_km and M <= 512 and N % 64 == 0) else 4
+    want = 5 if (M <= 2048 and N % 64 == 0 and (not b_km or N % 128 == 0)) else 4
     assert plan == want, (plan, want)                              # the few-rows path meant for this layout really ran
     assert rel(y, ref.float()) < 2e-5
     y2, _ = run(out_dtype=torch.float32)
