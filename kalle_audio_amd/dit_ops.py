@@ -83,6 +83,18 @@ class GradOut:
             return
         probs = []
         over = self.wgrad_overwrite or not self.accumulate or not self.sinks
+        # a gradient over far fewer rows than the others (the adaLN modulation weights see one row per clip) would add a round of
+        # 4-K-tile workgroups to the grouped launch and, being too short to slice, switch off the tail levelling for the whole
+        # group (adaLN step 255 -> 265 ms): it keeps its own GEMM
+        most = max(dy.shape[0] for _, dy, _ in items)
+        for name, dy, x in [it for it in items if it[1].shape[0] * 8 < most]:
+            s = self._sink(name)
+            if s is not None:
+                ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=not over)
+                self.grads[name] = None
+            else:
+                self.grads[name] = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+        items = [it for it in items if it[1].shape[0] * 8 >= most]
         for name, dy, x in items:
             s = self._sink(name)
             if s is not None:

@@ -23,6 +23,15 @@ timeout -k 10 300 python tools/llasa_bench.py 16 1024 3 --infer > $O/llasa.log 2
 cp $(find $O/prof -name "*kernel_stats.csv" | head -n 1) $O/kernel_stats.csv
 rm -rf $O/prof
 echo done
+# sweep of SURVEY 8(d)'s axes and the sampling path
+timeout -k 10 900 python tools/bench_sweep.py $O/sweep.md > $O/sweep.log 2>&1 || exit 1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sprof -- python3 $R/tools/sample_bench.py 1 20 > $O/sample_under_rocprof.log 2> $O/sprof.err || exit 1
+cp $(find $O/sprof -name "*kernel_stats.csv" | head -n 1) $O/sample_kernel_stats.csv
+rm -rf $O/sprof
+cd $R
+timeout -k 10 300 python tools/sample_bench.py 1 50 > $O/sample.log 2>&1 || exit 1
+echo extras done
 # PMC passes (each its own run, counters only + kernel trace): HBM-side fetch / write bytes and MFMA-pipe busy cycles
 if [ "$1" = "pmc" ]; then
   cd /tmp
