@@ -6,6 +6,8 @@ Objectives: "rectified_flow" runs sample_rf -> sample_discrete_euler exactly as 
 "v" is routed by the reference to third-party k-diffusion (`sample_k`, absent here) - this build runs the in-tree v-DDIM
 sampler instead (sampling.py:47-86, the call the reference keeps commented out at generation.py:236).  Inpainting /
 variations (init_audio, mask_args) are not carried over."""
+import os
+
 import numpy as np
 import torch
 
@@ -40,11 +42,24 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
         neg = {}
     for k in ("sigma_min", "sampler_type", "sigma_max", "rho"):      # k-diffusion knobs of the reference's call sites
         sampler_kwargs.pop(k, None)
+    # One sampler step is ~400 launches that take less GPU time than the host needs to issue them: the denoiser call is captured
+    # into a HIP graph once per shape signature and replayed (kalle_audio_amd/graph.py; bit-identical to the eager launches;
+    # KALLE_SAMPLE_GRAPH=0 keeps the eager path).  Only frozen models: a captured graph does not see parameter updates' new
+    # bf16 copies.
+    denoiser = model.model
+    frozen = not any(p.requires_grad for p in denoiser.parameters())
+    if steps >= 4 and frozen and os.environ.get("KALLE_SAMPLE_GRAPH", "1") != "0":     # (the samplers run under no_grad)
+        from ...graph import GraphedForward
+        g = getattr(model, "_kalle_graphed", None)
+        if g is None or g.fn is not denoiser:
+            g = GraphedForward(denoiser)
+            object.__setattr__(model, "_kalle_graphed", g)      # (not a submodule: keeps it out of state_dict / parameters)
+        denoiser = g
     if model.diffusion_objective == "v":
-        sampled = sample(model.model, noise, steps, eta, **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True,
+        sampled = sample(denoiser, noise, steps, eta, **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True,
                          rescale_cfg=True, **sampler_kwargs)
     elif model.diffusion_objective == "rectified_flow":
-        sampled = sample_discrete_euler(model.model, noise, steps, **cond_inputs, **neg, cfg_scale=cfg_scale,
+        sampled = sample_discrete_euler(denoiser, noise, steps, **cond_inputs, **neg, cfg_scale=cfg_scale,
                                         batch_cfg=True, rescale_cfg=True, **sampler_kwargs)
     else:
         raise ValueError(f"unknown diffusion objective {model.diffusion_objective!r}")

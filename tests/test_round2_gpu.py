@@ -45,6 +45,13 @@ def check_digests(f, grads, n, prefix="", tol=2e-2, strip="", skip=()):
     return cnt
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _drop_in_installed():
+    """`stable_audio_tools` / `model` / `flows` resolve to the drop-in for every test of this module, whatever subset runs"""
+    import kalle_audio_amd
+    kalle_audio_amd.install()
+
+
 @pytest.fixture(scope="module")
 def mods(dev):
     import kalle_audio_amd
@@ -384,6 +391,15 @@ def test_generate_diffusion_cond_end_to_end(dev):
     assert cosine(lat, f["v/latents"]) > 0.998, cosine(lat, f["v/latents"])
     audio = generate_diffusion_cond(model, **kw)
     assert cosine(audio, f["v/audio"]) > 0.998, cosine(audio, f["v/audio"])
+    # a frozen model samples through one HIP-graph replay per step (kalle_audio_amd/graph.py): same bits as the eager launches,
+    # also on the second call (replay of the cached graph with new inputs)
+    model.requires_grad_(False)
+    for _ in range(2):
+        lat_g = generate_diffusion_cond(model, return_latents=True, **kw)
+        assert getattr(model, "_kalle_graphed", None) is not None
+        assert torch.equal(lat_g, lat)
+    lat_s = generate_diffusion_cond(model, return_latents=True, **dict(kw, seed=e["seed"] + 1))
+    assert not torch.equal(lat_s, lat) and torch.isfinite(lat_s).all()
 
 
 @pytest.mark.parametrize("tag,objective,sampler,pre,seed", [("v_uniform", "v", "uniform", False, 62),
