@@ -141,68 +141,69 @@ class DiffusionTransformer(nn.Module):
             return output, info
         return output
 
+    # ---- helpers of forward(): classifier-free guidance as cond | uncond halves of one doubled batch ------------------------
+    @staticmethod
+    def _twice(v):
+        return None if v is None else torch.cat((v, v), dim=0)
+
+    @staticmethod
+    def _dropped(cond, prob):
+        """per-sample conditioning dropout (dit.py:263-272): a Bernoulli(prob) draw per clip zeroes that clip's conditioning;
+        host RNG glue, drawn exactly as the reference draws it (shape (B, 1, 1) on the tensor's device)"""
+        if cond is None:
+            return None
+        drop = torch.bernoulli(torch.full((cond.shape[0], 1, 1), prob, device=cond.device)).to(torch.bool)
+        return torch.where(drop, torch.zeros_like(cond), cond)
+
+    @staticmethod
+    def _with_unconditional(cond, negative=None, negative_mask=None):
+        """[cond | what the unconditional half sees]: zeros, or the negative prompt with its masked-out tokens zeroed
+        (dit.py:288-307)"""
+        if cond is None:
+            return None
+        other = torch.zeros_like(cond)
+        if negative is not None:
+            other = negative if negative_mask is None else torch.where(negative_mask.to(torch.bool).unsqueeze(2), negative, other)
+        return torch.cat((cond, other), dim=0)
+
+    @staticmethod
+    def _guided(both, scale, phi):
+        """uncond + scale * (cond - uncond), optionally rescaled towards the conditional output's per-position std over
+        channels (dit.py:345-360)"""
+        cond_out, uncond_out = both.chunk(2, dim=0)
+        guided = uncond_out + (cond_out - uncond_out) * scale
+        if phi == 0.0:
+            return guided
+        ratio = cond_out.std(dim=1, keepdim=True) / guided.std(dim=1, keepdim=True)
+        return phi * (guided * ratio) + (1 - phi) * guided
+
     def forward(self, x, t, cross_attn_cond=None, cross_attn_cond_mask=None, negative_cross_attn_cond=None,
                 negative_cross_attn_mask=None, input_concat_cond=None, global_embed=None,
                 negative_global_embed=None, prepend_cond=None, prepend_cond_mask=None, cfg_scale=1.0,
                 cfg_dropout_prob=0.0, causal=False, scale_phi=0.0, mask=None, return_info=False, **kwargs):
-        assert causal == False, "Causal mode is not supported for DiffusionTransformer"  # noqa: E712
-        if cross_attn_cond_mask is not None:
-            cross_attn_cond_mask = None  # the reference disables conditioning masks (dit.py:254-257)
+        assert not causal, "Causal mode is not supported for DiffusionTransformer"
+        cross_attn_cond_mask = None             # the reference disables conditioning masks (dit.py:254-257)
         if prepend_cond_mask is not None:
             prepend_cond_mask = prepend_cond_mask.bool()
-        # CFG dropout (dit.py:263-272): per-sample bernoulli, conditioning zeroed - host RNG glue as the reference
-        if cfg_dropout_prob > 0.0:
-            if cross_attn_cond is not None:
-                keep = torch.bernoulli(torch.full((cross_attn_cond.shape[0], 1, 1), cfg_dropout_prob,
-                                                  device=cross_attn_cond.device)).to(torch.bool)
-                cross_attn_cond = torch.where(keep, torch.zeros_like(cross_attn_cond), cross_attn_cond)
-            if prepend_cond is not None:
-                keep = torch.bernoulli(torch.full((prepend_cond.shape[0], 1, 1), cfg_dropout_prob,
-                                                  device=prepend_cond.device)).to(torch.bool)
-                prepend_cond = torch.where(keep, torch.zeros_like(prepend_cond), prepend_cond)
-        if cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None):
-            # classifier-free guidance: cond / uncond batched on dim 0 (dit.py:275-364)
-            batch_inputs = torch.cat([x, x], dim=0)
-            batch_timestep = torch.cat([t, t], dim=0)
-            batch_global_cond = torch.cat([global_embed, global_embed], dim=0) if global_embed is not None else None
-            batch_input_concat_cond = (torch.cat([input_concat_cond, input_concat_cond], dim=0)
-                                       if input_concat_cond is not None else None)
-            batch_cond = batch_cond_masks = None
-            if cross_attn_cond is not None:
-                null_embed = torch.zeros_like(cross_attn_cond)
-                if negative_cross_attn_cond is not None:
-                    if negative_cross_attn_mask is not None:
-                        negative_cross_attn_mask = negative_cross_attn_mask.to(torch.bool).unsqueeze(2)
-                        negative_cross_attn_cond = torch.where(negative_cross_attn_mask, negative_cross_attn_cond,
-                                                               null_embed)
-                    batch_cond = torch.cat([cross_attn_cond, negative_cross_attn_cond], dim=0)
-                else:
-                    batch_cond = torch.cat([cross_attn_cond, null_embed], dim=0)
-            batch_prepend_cond = batch_prepend_cond_mask = None
-            if prepend_cond is not None:
-                batch_prepend_cond = torch.cat([prepend_cond, torch.zeros_like(prepend_cond)], dim=0)
-                if prepend_cond_mask is not None:
-                    batch_prepend_cond_mask = torch.cat([prepend_cond_mask, prepend_cond_mask], dim=0)
-            batch_masks = torch.cat([mask, mask], dim=0) if mask is not None else None
-            batch_output = self._forward(batch_inputs, batch_timestep, cross_attn_cond=batch_cond,
-                                         cross_attn_cond_mask=batch_cond_masks, mask=batch_masks,
-                                         input_concat_cond=batch_input_concat_cond, global_embed=batch_global_cond,
-                                         prepend_cond=batch_prepend_cond, prepend_cond_mask=batch_prepend_cond_mask,
-                                         return_info=return_info, **kwargs)
-            if return_info:
-                batch_output, info = batch_output
-            cond_output, uncond_output = torch.chunk(batch_output, 2, dim=0)
-            cfg_output = uncond_output + (cond_output - uncond_output) * cfg_scale
-            if scale_phi != 0.0:
-                cond_out_std = cond_output.std(dim=1, keepdim=True)
-                out_cfg_std = cfg_output.std(dim=1, keepdim=True)
-                output = scale_phi * (cfg_output * (cond_out_std / out_cfg_std)) + (1 - scale_phi) * cfg_output
-            else:
-                output = cfg_output
-            if return_info:
-                return output, info
-            return output
-        return self._forward(x, t, cross_attn_cond=cross_attn_cond, cross_attn_cond_mask=cross_attn_cond_mask,
-                             input_concat_cond=input_concat_cond, global_embed=global_embed,
-                             prepend_cond=prepend_cond, prepend_cond_mask=prepend_cond_mask, mask=mask,
-                             return_info=return_info, **kwargs)
+        if cfg_dropout_prob > 0.0:              # training: cross-attention draw first, prepend draw second (RNG order of :263-272)
+            cross_attn_cond = self._dropped(cross_attn_cond, cfg_dropout_prob)
+            prepend_cond = self._dropped(prepend_cond, cfg_dropout_prob)
+        guided = cfg_scale != 1.0 and (cross_attn_cond is not None or prepend_cond is not None)
+        if not guided:
+            return self._forward(x, t, cross_attn_cond=cross_attn_cond, cross_attn_cond_mask=cross_attn_cond_mask,
+                                 input_concat_cond=input_concat_cond, global_embed=global_embed,
+                                 prepend_cond=prepend_cond, prepend_cond_mask=prepend_cond_mask, mask=mask,
+                                 return_info=return_info, **kwargs)
+        # one pass over [conditional | unconditional] (dit.py:275-364); the global embedding is shared by both halves
+        result = self._forward(self._twice(x), self._twice(t),
+                               cross_attn_cond=self._with_unconditional(cross_attn_cond, negative_cross_attn_cond,
+                                                                        negative_cross_attn_mask),
+                               cross_attn_cond_mask=None, mask=self._twice(mask),
+                               input_concat_cond=self._twice(input_concat_cond), global_embed=self._twice(global_embed),
+                               prepend_cond=self._with_unconditional(prepend_cond),
+                               prepend_cond_mask=self._twice(prepend_cond_mask) if prepend_cond is not None else None,
+                               return_info=return_info, **kwargs)
+        if return_info:
+            both, info = result
+            return self._guided(both, cfg_scale, scale_phi), info
+        return self._guided(result, cfg_scale, scale_phi)

@@ -1,5 +1,6 @@
-"""Drop-in for stable_audio_tools/training/losses/losses.py: LossModule (6-15), ValueLoss (16-23), MSELoss (44-69),
-MultiLoss (85-101).  MSELoss runs the fused masked-MSE kernel (forward value + gradient in one pass)."""
+"""Loss terms of the training wrappers (reference interface: stable_audio_tools/training/losses/losses.py - LossModule 6-15,
+ValueLoss 16-23, MSELoss 44-69, MultiLoss 85-101; same class names, constructor arguments and `forward(info)` contract).
+MSELoss is the fused masked-MSE kernel (value and gradient from one pass over output / target)."""
 import typing as tp
 
 from torch import nn
@@ -8,55 +9,59 @@ from .... import functional as KF
 
 
 class LossModule(nn.Module):
+    """a named, weighted term computed from the step's `info` dict"""
+
     def __init__(self, name: str, weight: float = 1.0):
         super().__init__()
-        self.name = name
-        self.weight = weight
+        self.name, self.weight = name, weight
 
     def forward(self, info, *args, **kwargs):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__} does not define its term")
 
 
 class ValueLoss(LossModule):
+    """a value some other part of the step already left in `info`"""
+
     def __init__(self, key: str, name, weight: float = 1.0):
-        super().__init__(name=name, weight=weight)
+        LossModule.__init__(self, name, weight)
         self.key = key
 
     def forward(self, info):
-        return self.weight * info[self.key]
+        return info[self.key] * self.weight
 
 
 class MSELoss(LossModule):
     def __init__(self, key_a: str, key_b: str, weight: float = 1.0, mask_key: str = None, name: str = 'mse_loss'):
-        super().__init__(name=name, weight=weight)
-        self.key_a = key_a
-        self.key_b = key_b
-        self.mask_key = mask_key
+        LossModule.__init__(self, name, weight)
+        self.key_a, self.key_b, self.mask_key = key_a, key_b, mask_key
+
+    def _mask(self, info):
+        """(B, T) boolean mask or None; the reference broadcasts a (B, 1, T) mask over channels (losses.py:57-63)"""
+        mask = info.get(self.mask_key) if self.mask_key is not None else None
+        if mask is not None and mask.ndim == 3:
+            if mask.shape[1] != 1:
+                raise NotImplementedError("per-channel loss masks")
+            mask = mask[:, 0]
+        return mask
 
     def forward(self, info):
-        a, b = info[self.key_a], info[self.key_b]
-        mask = None
-        if self.mask_key is not None and self.mask_key in info and info[self.mask_key] is not None:
-            mask = info[self.mask_key]
-            if mask.ndim == 3:
-                if mask.shape[1] != 1:
-                    raise NotImplementedError("per-channel loss masks")
-                mask = mask[:, 0]
-        if a.ndim != 3:
+        output, target = info[self.key_a], info[self.key_b]
+        if output.ndim != 3:
             raise NotImplementedError("MSELoss kernel expects (B, C, T) tensors")
-        return KF.MSELossFn.apply(a, b, mask, float(self.weight))     # (the target's gradient exists only with enable_grad)
+        # (the target's gradient exists only when the pretransform is trained: enable_grad)
+        return KF.MSELossFn.apply(output, target, self._mask(info), float(self.weight))
 
 
 class MultiLoss(nn.Module):
+    """sum of the terms, in list order, plus each term by name (what the wrappers log)"""
+
     def __init__(self, losses: tp.List[LossModule]):
         super().__init__()
         self.losses = nn.ModuleList(losses)
 
     def forward(self, info):
-        total_loss = 0
-        losses = {}
-        for loss_module in self.losses:
-            module_loss = loss_module(info)
-            total_loss = total_loss + module_loss
-            losses[loss_module.name] = module_loss
-        return total_loss, losses
+        parts = {term.name: term(info) for term in self.losses}
+        total = 0
+        for value in parts.values():
+            total = total + value
+        return total, parts
