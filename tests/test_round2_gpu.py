@@ -580,6 +580,30 @@ def test_second_consumers_of_block_outputs_and_context(mods, dev):
     assert rel(dx0, dx) > 1e-2 and rel(dctx0, dctx) > 1e-2
 
 
+def test_overlapped_optimizer_equals_single_pass(dev):
+    """the fused Adam launched per bucket from the backward hooks on the optimizer stream (engine.py, default on a GPU) against
+    the single pass at the end of the step: same weights, moments and bf16 mirror after three steps with gradient accumulation,
+    up to the order of the fp32 atomics inside the gradients"""
+    from kalle_audio_amd import engine
+    lat, noise, t, cond = _batch(dev, 4, 6)
+    res = []
+    for overlap in (True, False):
+        m = _small_dit(dev)
+        tr = engine.DataParallelTrainer(m, lr=1e-3, optimizer="AdamW", weight_decay=0.01, grad_accum_steps=2,
+                                        lr_schedule=lambda s: engine.cosine_with_warmup(s, 1, 20))
+        assert tr.overlap_adam
+        tr.overlap_adam = overlap
+        for i in range(6):
+            s_ = slice(0, 2) if i % 2 == 0 else slice(2, 4)
+            tr.train_step(m, lat[s_], t[s_], noise[s_], _slice_cond(cond, s_))
+        torch.cuda.synchronize()
+        assert tr.step_count == 3
+        res.append((tr.flat.param.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.flat.param_bf16.float(), tr.last_lr))
+    a, b = res
+    assert a[4] == b[4]
+    assert rel(a[0], b[0]) < 1e-5 and rel(a[1], b[1]) < 5e-3 and rel(a[2], b[2]) < 5e-3 and rel(a[3], b[3]) < 1e-3
+
+
 def test_trainer_state_dict_roundtrip_resumes(dev):
     """DataParallelTrainer.state_dict / load_state_dict: weights, Adam moments, step, accumulation phase and the EMA; a
     restored trainer continues exactly like the original"""
