@@ -218,6 +218,8 @@ class DataParallelTrainer:
         self._opt_stream = torch.cuda.Stream(device=device) if self.overlap_adam else None
         self._opt_done = set()            # bucket keys whose Adam slice of the current optimizer step has been queued
         self._opt_lr = None               # learning rate of the optimizer step in progress (set when its backward starts)
+        self._overlap_now = False         # decided per optimizer step: only where the backward GEMMs are long enough to hide it
+        self.overlap_min_rows = int(os.environ.get("KALLE_OVERLAP_ADAM_MIN_ROWS", "4096"))
         for n, blk in self.blocks:
             pre = n + "."
             blk._kalle_grad_sinks = {k[len(pre):]: self.flat.grad_view(k) for k in self.flat.names if k.startswith(pre)}
@@ -250,7 +252,7 @@ class DataParallelTrainer:
         if not self._boundary():
             return
         key = blk._kalle_bucket_key
-        if not self.overlap_adam:
+        if not self._overlap_now:
             self._allreduce(self.flat.bucket_grad(key))
             return
         # the bucket's all-reduce, then its Adam slice, on the optimizer stream behind an event of the compute stream
@@ -297,7 +299,7 @@ class DataParallelTrainer:
             for key in ("_rest", "_vae"):
                 if key in self.flat.bucket_range:
                     self._allreduce(self.flat.bucket_grad(key))
-        if self.overlap_adam and self._boundary():
+        if self._overlap_now and self._boundary():
             # what the bucket hooks did not cover (embedders, in / out projections, a trained VAE): communicated above, waited
             # for and updated on the optimizer stream too; the compute stream then waits for that stream ONCE - the time it
             # sits there is what neither the all-reduces nor the optimizer slices managed to hide behind the backward pass
@@ -381,6 +383,9 @@ class DataParallelTrainer:
                         self.flat.bucket_grad(key).zero_()     # autograd accumulates (+=) into these views
         if self._boundary():
             self._begin_optimizer_step()
+            # at small batches (B = 16: 2016 rows) the backward GEMMs are short, latency-bound launches that the optimizer's
+            # 31.5 GB of traffic slows down by as much as it hides (33.6 -> 33.8 ms); from B = 64 on it pays (73.3 -> 72.6 ms)
+            self._overlap_now = self.overlap_adam and (rows >= self.overlap_min_rows or not self.blocks)
         loss.backward()
         self._finish_comm()
         if self._boundary():
@@ -409,7 +414,7 @@ class DataParallelTrainer:
     def optimizer_step(self):
         if self._opt_lr is None:                           # called directly (not through backward())
             self._begin_optimizer_step()
-        if not (self.overlap_adam and len(self._opt_done) == len(self.flat.bucket_keys)):
+        if not (self._overlap_now and len(self._opt_done) == len(self.flat.bucket_keys)):
             # one fused pass over whatever has not been updated yet (everything, without the overlapped slices)
             if self._opt_done:
                 for key in self.flat.bucket_keys:

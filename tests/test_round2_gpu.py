@@ -593,6 +593,7 @@ def test_overlapped_optimizer_equals_single_pass(dev):
                                         lr_schedule=lambda s: engine.cosine_with_warmup(s, 1, 20))
         assert tr.overlap_adam
         tr.overlap_adam = overlap
+        tr.overlap_min_rows = 0                 # (by default only micro-batches of >= 4096 rows overlap)
         for i in range(6):
             s_ = slice(0, 2) if i % 2 == 0 else slice(2, 4)
             tr.train_step(m, lat[s_], t[s_], noise[s_], _slice_cond(cond, s_))
@@ -601,7 +602,9 @@ def test_overlapped_optimizer_equals_single_pass(dev):
         res.append((tr.flat.param.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.flat.param_bf16.float(), tr.last_lr))
     a, b = res
     assert a[4] == b[4]
-    assert rel(a[0], b[0]) < 1e-5 and rel(a[1], b[1]) < 5e-3 and rel(a[2], b[2]) < 5e-3 and rel(a[3], b[3]) < 1e-3
+    # (Adam's first steps move every weight by ~lr whatever the gradient's size: an element whose tiny gradient changes sign with
+    # the atomics' order moves the other way - 2e-5 of the weight norm was seen between two runs of the SAME mode)
+    assert rel(a[0], b[0]) < 2e-4 and rel(a[1], b[1]) < 5e-3 and rel(a[2], b[2]) < 5e-3 and rel(a[3], b[3]) < 1e-3
 
 
 def test_trainer_state_dict_roundtrip_resumes(dev):
@@ -717,6 +720,7 @@ assert tr._pending == []
 os.environ["KALLE_FORCE_COMM"] = "1"
 for name, cd in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
     m = R._small_dit(dev); tr = engine.DataParallelTrainer(m, lr=1e-3, optimizer="Adam", comm_dtype=cd)
+    tr.overlap_min_rows = 0          # fp32 buckets: all-reduce wait + Adam slice per bucket on the optimizer stream
     tr.comm_timing = []
     for _ in range(2): tr.train_step(m, lat, t, noise, cond)
     torch.cuda.synchronize()
