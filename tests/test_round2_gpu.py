@@ -1043,3 +1043,38 @@ def test_encode_latents_example_writes_reference_latent_files(dev, tmp_path):
         ref = ae.encode(x)[0]
     assert z.shape == (8, len(mono) // 40) and z.dtype == np.float32
     assert rel(torch.from_numpy(z), ref) < 1e-5
+
+
+def test_gemm_random_shapes_every_dispatch_path(dev):
+    """seeded sweep over (M, N, K, layout, output type, epilogue options): whichever kernel the dispatcher picks - single-row
+    GEMV, small tiles (plan 5), few-rows slabs (4), 256 x 128 (2), 256 x 256 (3), first-generation 128 x 128 (1) - the result
+    matches fp64 on the same bf16 operands (fp32 accumulation: 3e-5 for fp32 outputs, one bf16 rounding for bf16 outputs)"""
+    from kalle_audio_amd import ops, _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(1234)
+    seen = set()
+    for it in range(48):
+        M = int(rng.choice([1, 7, 16, 100, 126, 252, 504, 520, 1000, 2016, 2100, 3000, 4100]))
+        N = int(rng.choice([64, 128, 192, 768, 1472, 1536, 2048])) if it % 5 else int(rng.choice([8, 24, 1000]))
+        K = int(rng.choice([8, 64, 200, 768, 1536, 2056]))
+        b_km = bool(rng.randint(2))
+        f32 = bool(rng.randint(2))
+        g = torch.Generator().manual_seed(it)
+        a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+        b = (torch.randn(K, N, generator=g) if b_km else torch.randn(N, K, generator=g)).to(dev).to(torch.bfloat16)
+        ref = a.double() @ (b.double() if b_km else b.double().T)
+        kw = dict(b_kmajor=b_km, out_dtype=torch.float32 if f32 else torch.bfloat16)
+        opt = int(rng.randint(4))
+        if opt & 1:
+            bias = torch.randn(N, generator=g).to(dev)
+            kw["bias"] = bias
+            ref = ref + bias.double()
+        if (opt & 2) and f32:
+            res = torch.randn(M, N, generator=g).to(dev)
+            kw["residual"] = res
+            ref = ref + res.double()
+        y = ops.gemm(a, b, **kw)
+        seen.add(lib.kalle_gemm_last_plan() & 255 if M > 1 else 0)
+        tol = 3e-5 if f32 else 4e-3
+        assert y.shape == (M, N) and rel(y, ref.float()) < tol, (it, M, N, K, b_km, f32, opt, rel(y, ref.float()))
+    assert {1, 2, 4, 5} <= seen, seen       # (the sweep really went through the different kernels)
