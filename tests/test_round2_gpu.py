@@ -1078,3 +1078,47 @@ def test_gemm_random_shapes_every_dispatch_path(dev):
         tol = 3e-5 if f32 else 4e-3
         assert y.shape == (M, N) and rel(y, ref.float()) < tol, (it, M, N, K, b_km, f32, opt, rel(y, ref.float()))
     assert {1, 2, 4, 5} <= seen, seen       # (the sweep really went through the different kernels)
+
+
+def test_conv_random_shapes_against_torch(dev):
+    """seeded sweep over the conv kernels' dispatch (position-per-lane tiles of 2 / 8 / 16 channels, 8-wave tiles, channels-per-lane
+    kernel with and without the input-channel split, strided and transposed forms): channel counts that are no multiple of the
+    tile widths, kernel sizes 1-16, dilations, strides, asymmetric padding, odd lengths - against torch's fp32 conv (1e-4)"""
+    import torch.nn.functional as F
+    from kalle_audio_amd import conv_ops
+    rng = np.random.RandomState(77)
+    for it in range(40):
+        B = int(rng.choice([1, 2, 3]))
+        Cin = int(rng.choice([1, 2, 3, 8, 17, 32, 64, 130, 256, 520]))
+        Cout = int(rng.choice([1, 2, 6, 16, 17, 24, 64, 100, 256, 512]))
+        g = torch.Generator().manual_seed(1000 + it)
+        if it % 4 == 3:                                   # transposed conv (decoder up-sampling): K = 2 s + s % 2, pad = ceil(s / 2)
+            stride = int(rng.choice([2, 4, 5, 8]))
+            K, pad = 2 * stride + stride % 2, (stride + 1) // 2
+            L = int(rng.choice([5, 27, 130, 431]))
+            x = torch.randn(B, Cin, L, generator=g).to(dev)
+            v = (torch.randn(Cin, Cout, K, generator=g) * 0.2).to(dev)
+            gg = (1 + 0.1 * torch.randn(Cin, generator=g)).to(dev)
+            bias = torch.randn(Cout, generator=g).to(dev)
+            w = gg.view(-1, 1, 1) * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+            ref = F.conv_transpose1d(x, w, bias, stride=stride, padding=pad)
+            y = conv_ops.conv_transpose1d(x, conv_ops.weight_norm_fold(v, gg, transposed=True), bias, Cout=Cout, K=K, stride=stride,
+                                          padding=pad)
+        else:
+            stride = int(rng.choice([1, 1, 1, 2, 4, 8]))
+            K = int(rng.choice([1, 2, 3, 7, 11])) if stride == 1 else 2 * stride
+            dil = int(rng.choice([1, 3, 9])) if stride == 1 else 1
+            total = dil * (K - 1)
+            pad = (stride + 1) // 2 if stride > 1 else total // 2
+            pr = (total - pad) if stride == 1 else pad     # torch 'same' for even kernels: the odd zero goes to the right
+            L = int(rng.choice([40, 203, 1000, 4099])) + total
+            x = torch.randn(B, Cin, L, generator=g).to(dev)
+            v = (torch.randn(Cout, Cin, K, generator=g) * 0.2).to(dev)
+            gg = (1 + 0.1 * torch.randn(Cout, generator=g)).to(dev)
+            bias = torch.randn(Cout, generator=g).to(dev) if it % 3 else None
+            w = gg.view(-1, 1, 1) * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+            ref = F.conv1d(F.pad(F.elu(x), (pad, pr)), w, bias, stride=stride, dilation=dil)
+            y = conv_ops.conv1d(x, conv_ops.weight_norm_fold(v, gg), bias, Cout=Cout, K=K, stride=stride, padding=pad,
+                                dilation=dil, act=2, pad_right=pr)
+        assert y.shape == ref.shape, (it, y.shape, ref.shape)
+        assert rel(y, ref) < 1e-4, (it, B, Cin, Cout, K, stride, rel(y, ref))
