@@ -1122,3 +1122,35 @@ def test_conv_random_shapes_against_torch(dev):
                                 dilation=dil, act=2, pad_right=pr)
         assert y.shape == ref.shape, (it, y.shape, ref.shape)
         assert rel(y, ref) < 1e-4, (it, B, Cin, Cout, K, stride, rel(y, ref))
+
+
+def test_attention_random_lengths_and_groups(dev):
+    """seeded sweep of the fused attention (forward, both backward kernels) over query / key lengths around the 128-row block
+    boundaries, GQA group sizes 1 / 2 / 4 and key masks, against fp32 torch on the same bf16 operands"""
+    from kalle_audio_amd import ops
+    from test_kernels_gpu import _attn_ref, _mk
+    rng = np.random.RandomState(5)
+    for it in range(14):
+        Nq = int(rng.choice([1, 15, 126, 128, 129, 257, 300]))
+        Nk = int(rng.choice([2, 17, 127, 128, 130, 256, 259]))
+        Hkv = int(rng.choice([1, 2]))
+        H = Hkv * int(rng.choice([1, 2, 4]))
+        B, D, Dc = 2, H * 64, Hkv * 64
+        q = (_mk((B, Nq, D), dev, seed=300 + it) * 0.8).bfloat16()
+        kv = (_mk((B, Nk, 2 * Dc), dev, seed=400 + it) * 0.8).bfloat16()
+        dout = _mk((B, Nq, D), dev, seed=500 + it).bfloat16()
+        mask = None
+        if it % 2:
+            mask = torch.rand(B, Nk, device=dev) > 0.3
+            mask[:, 0] = True
+        qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+        k, v = kvr.chunk(2, -1)
+        ref = _attn_ref(qr, k, v, mask, None, H, Hkv)
+        ref.backward(dout.float())
+        out, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H, Hkv=Hkv,
+                                     Nq=Nq, Nk=Nk, key_mask=mask)
+        assert rel(out, ref) < 1e-2, (it, Nq, Nk, H, Hkv, rel(out, ref))
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        ops.attention_bwd(q, kv, kv, out, dout, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc,
+                          B=B, H=H, Hkv=Hkv, Nq=Nq, Nk=Nk, key_mask=mask)
+        assert rel(dq, qr.grad) < 2e-2 and rel(dkv, kvr.grad) < 2e-2, (it, Nq, Nk, H, Hkv, rel(dq, qr.grad), rel(dkv, kvr.grad))
