@@ -57,8 +57,9 @@ typedef struct kalle_gemm_epilogue {
     int32_t c_row_offset;
     const uint8_t* row_mask; /* [M] or NULL: rows with 0 contribute 0 before the residual add
                               * (Attention zeroes padded query rows after to_out, transformer.py:543-545) */
-    /* fused SwiGLU (transformer.py:216-219), bf16 C, 256x256 kernel only (returns KALLE_ERR_UNSUPPORTED otherwise -
-     * the caller then runs the GEMM and kalle_swiglu_* separately):
+    /* fused SwiGLU (transformer.py:216-219), bf16 C; in the 256x256 kernel (glu_inner % 128 == 0) and, forward only, in the
+     * small-tile kernels of the few-row path (M <= 2048, glu_inner % 32 == 0); KALLE_ERR_UNSUPPORTED otherwise - the caller
+     * then runs the GEMM and kalle_swiglu_* separately:
      *   glu_mode 1 (forward,  a_kmajor=0,b_kmajor=0, N = 2*glu_inner): C = h = x W^T + b  [M][2*inner]  AND
      *              glu_aux = act [M][inner] bf16 = h[:, j] * silu(h[:, inner + j])
      *   glu_mode 2 (backward, a_kmajor=0,b_kmajor=1, N = glu_inner):   acc = d(act); glu_aux = h [M][2*inner] bf16;
@@ -67,11 +68,13 @@ typedef struct kalle_gemm_epilogue {
     int32_t glu_inner;
     void* glu_aux;
     float* glu_dbias;
-    /* optional scratch for the few-rows path (sampling at generation batch sizes, small training batches): with
+    /* optional scratch for the few-rows paths (sampling at generation batch sizes, small training batches): with
      * workspace_bytes >= 8 * M * N the dispatcher may cut K into up to workspace_bytes / (4 M N) slices, each writing its
-     * partial result as an fp32 [M][N] slab (so that a GEMM with M <= 4096 rows fills 256 CUs), and sum the slabs in a fixed
-     * order + apply the epilogue in a finishing pass (bitwise reproducible).  The library never
-     * allocates: no workspace, no such path.  Contents are undefined afterwards; one workspace per stream. */
+     * partial result as an fp32 [M][N] slab, and sum the slabs in a fixed order + apply the epilogue in a finishing pass
+     * (bitwise reproducible).  Used for long K only: with M <= 2048 rows and N % 64 == 0 (N % 128 for a k-major B) the
+     * dispatcher first cuts the OUTPUT into 64 x 64 ... 128 x 128 tiles over the whole K (two wave groups per tile, epilogue in
+     * the same launch, no scratch), and takes K slices only beyond ~2048 deep.  The library never allocates: no workspace, no
+     * sliced path.  Contents are undefined afterwards; one workspace per stream. */
     void* workspace;
     int64_t workspace_bytes;
 } kalle_gemm_epilogue;
@@ -81,8 +84,9 @@ int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int
                     const kalle_gemm_epilogue* ep, void* stream);
 
 /* which kernel the calling thread's most recent kalle_gemm_bf16 used: low byte 1 = gemm_bf16_kernel (128x128,
- * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 8 == 0), 3 = gemm3_kernel (256x256, 2 stages); bits 8.. =
- * split-K factor */
+ * register-staged, any shape), 2 = gemm2_kernel (256x128, LDS-DMA 3-stage ring, K % 8 == 0), 3 = gemm3_kernel (256x256, 2 stages),
+ * 4 = few-rows K slices (slabs + finishing pass), 5 = small tiles with two wave groups (gemm2_ks2_kernel); for 1-4 bits 8.. =
+ * split-K factor, for 5 bits 8-11 / 12-15 = tile rows / columns in units of 64, bits 16.. = K slices */
 int kalle_gemm_last_plan(void);
 
 /* ------------------------------------------------------------------------------------------------
