@@ -111,7 +111,8 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
     if prof is not None:
         e1.record()
         plan = lib.kalle_gemm_last_plan()
-        kname = {1: "gemm_bf16_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel", 4: "gemm2_splitk+finish"}.get(plan & 255, "gemm")
+        kname = {1: "gemm_bf16_kernel", 2: "gemm2_kernel", 3: "gemm3_kernel", 4: "gemm2_splitk+finish",
+                 5: "gemm2_ks2_kernel"}.get(plan & 255, "gemm")
         variant = "%s<%d,%d,%d%s>" % (kname, int(a_kmajor), int(b_kmajor), int(out.dtype == torch.float32),
                                       ",glu%d" % glu_mode if glu_mode else "")      # (the fused-SwiGLU kernels are their own rows)
         abytes = 2.0 * (M * K + N * K) + M * N * out.element_size() + (4.0 * M * N if residual is not None else 0.0)
