@@ -654,6 +654,222 @@ __global__ __launch_bounds__(128 / (16 * OT) * 64, OT == 1 ? 4 : 2) void attn_bw
     }
 }
 
+// ---- fused backward for one block of queries AND keys (the DiT's self-attention: 126 tokens) ----------------------------------
+// At this size the two-kernel backward is bound by HBM, not by MFMA: each kernel re-reads q, k, v and dO.  Here one workgroup per
+// (batch, head) stages all four tiles once (4 x 20 KiB = exactly half a CU's LDS, so two workgroups share a CU and one's staging
+// runs under the other's MFMAs; the per-row softmax statistics live in the 32 pad bytes of the tile rows) and runs both
+// orientations back to back on them: keys as owners -> dK, dV (queries streamed from LDS), then queries as owners -> dQ (keys
+// streamed from LDS).  No barrier between the two: LDS is read-only after staging.  Same arithmetic per element as the two
+// kernels (same operand rounding, same sum order per accumulator).
+__device__ __forceinline__ float& row_stat(char* tile, int row, int slot) {
+    return *reinterpret_cast<float*>(tile + row * AT_STRIDE + 128 + 4 * slot);
+}
+
+__global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
+    constexpr int NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RQ = smem;                  // pad slot 0: -lse * log2 e (-inf past the end), slot 1: -delta * scale
+    char* RD = smem + AT_TILE;        // dO
+    char* RK = smem + 2 * AT_TILE;    // pad slot 0: key bias (0 valid / -inf masked or past the end)
+    char* RV = smem + 3 * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int N = p.Nq, Nk = p.Nk;
+    const bf16_t* qb = p.q + (int64_t)b * N * p.ldq + p.q_off + h * 64;
+    const bf16_t* kb = p.k + (int64_t)b * Nk * p.ldk + p.k_off + h * 64;
+    const bf16_t* vb = p.v + (int64_t)b * Nk * p.ldv + p.v_off + h * 64;
+    const bf16_t* dob = p.dout + (int64_t)b * N * p.ldo + h * 64;
+
+    // ---- staging: all global loads in flight together, then rotary + LDS writes
+    {
+        TileRegs<NT> tq, td, tk, tv;
+        tile_load<NT>(tq, qb, p.ldq, 0, N, p.rot, tid);
+        tile_load<NT>(td, dob, p.ldo, 0, N, 0, tid);
+        tile_load<NT>(tk, kb, p.ldk, 0, Nk, p.rot, tid);
+        tile_load<NT>(tv, vb, p.ldv, 0, Nk, 0, tid);
+        // delta[q] = sum_d dO[q][d] O[q][d]: 4 threads per row, O straight from global (in flight with the tiles)
+        const int drow = tid >> 2, dq4 = tid & 3;
+        i32x4 o0v = i32x4{0, 0, 0, 0}, o1v = i32x4{0, 0, 0, 0};
+        if (drow < N) {
+            const bf16_t* op = p.out + ((int64_t)b * N + drow) * p.ldo + h * 64 + 16 * dq4;
+            o0v = *reinterpret_cast<const i32x4*>(op);
+            o1v = *reinterpret_cast<const i32x4*>(op + 8);
+        }
+        tile_store<NT>(RQ, tq, 0, N, p.cosT, p.sinT, p.rot, tid, p.qpos);
+        tile_store<NT>(RD, td, 0, N, nullptr, nullptr, 0, tid);
+        tile_store<NT>(RK, tk, 0, Nk, p.cosT, p.sinT, p.rot, tid);
+        tile_store<NT>(RV, tv, 0, Nk, nullptr, nullptr, 0, tid);
+        __syncthreads();
+        const i32x4 d0v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4);
+        const i32x4 d1v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4 + 16);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dl += bf16lo((uint32_t)o0v[e]) * bf16lo((uint32_t)d0v[e]) + bf16hi((uint32_t)o0v[e]) * bf16hi((uint32_t)d0v[e]);
+            dl += bf16lo((uint32_t)o1v[e]) * bf16lo((uint32_t)d1v[e]) + bf16hi((uint32_t)o1v[e]) * bf16hi((uint32_t)d1v[e]);
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        dl += __shfl_xor(dl, 2, 64);
+        if (dq4 == 0) {
+            const bool ok = drow < N;
+            row_stat(RQ, drow, 0) = ok ? -p.lse[((int64_t)b * p.H + h) * N + drow] * LOG2E : -INFINITY;
+            row_stat(RQ, drow, 1) = ok ? -dl * SM_SCALE : 0.f;
+            if (ok) p.delta[((int64_t)b * p.H + h) * N + drow] = dl;      // (kept for callers that look at it)
+        } else if (dq4 == 1) {
+            bool ok = drow < Nk;
+            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + drow] != 0;
+            row_stat(RK, drow, 0) = ok ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+    }
+    const f32x2 c2 = f32x2{SM_SCALE_LOG2E, SM_SCALE_LOG2E}, sc2 = f32x2{SM_SCALE, SM_SCALE};
+    const int orow = wave * 16;                  // this wave's 16 owner rows (keys in phase A, queries in phase B)
+
+    // =============================== phase A: keys own, queries stream -> dK, dV
+    if (orow < Nk) {
+        bf16x8 y1[2], y2[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { y1[s] = rowfrag(RK, orow, s, lane); y2[s] = rowfrag(RV, orow, s, lane); }
+        const float ca = row_stat(RK, orow + li, 0);
+        f32x4 g1[4], g2[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { g1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; g2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (32 * pr >= N) break;
+            f32x4 sa[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = 32 * pr + 16 * t;
+                sa[t] = f32x4{ca, ca, ca, ca};
+                dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RQ, rb, s, lane), y1[s], sa[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RD, rb, s, lane), y2[s], dp[t], 0, 0, 0);
+                }
+                f32x4 ra, rbv;          // streamed queries rb + 4g + r: -lse * log2 e, -delta * scale
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ra[r] = row_stat(RQ, rb + 4 * g + r, 0); rbv[r] = row_stat(RQ, rb + 4 * g + r, 1); }
+                mfma_results_ready();
+                const f32x2 ea = pk_fma(lo2(sa[t]), c2, lo2(ra)), eb = pk_fma(hi2(sa[t]), c2, hi2(ra));
+                const f32x4 pv = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                       __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                const f32x2 ta = pk_fma(lo2(dp[t]), sc2, lo2(rbv)), tb = pk_fma(hi2(dp[t]), sc2, hi2(rbv));
+                sa[t] = pv;
+                dp[t] = pv * f32x4{ta[0], ta[1], tb[0], tb[1]};
+            }
+            const bf16x8 pb = pack_pair(sa[0], sa[1]), dsb = pack_pair(dp[0], dp[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                g2[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RQ, 32 * pr, 32 * pr + 16, 16 * dt, lane), dsb, g2[dt], 0, 0, 0);
+                g1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RD, 32 * pr, 32 * pr + 16, 16 * dt, lane), pb, g1[dt], 0, 0, 0);
+            }
+        }
+        const int oi = orow + li;
+        if (oi < Nk) {
+            if (p.rot) {
+                const int hts = p.rot >> 5;
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) {
+                    if (ht >= hts) break;
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + (int64_t)oi * (p.rot >> 1) + 16 * ht + 4 * g);
+                    f32x4& lo = hts == 1 ? g2[0] : g2[ht];
+                    f32x4& hi = hts == 1 ? g2[1] : g2[ht + 2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = lo[r], bb = hi[r];
+                        lo[r] = a * c4[r] + bb * s4[r];
+                        hi[r] = bb * c4[r] - a * s4[r];
+                    }
+                }
+            }
+            bf16_t* dkp = p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + h * 64 + 4 * g;
+            bf16_t* dvp = p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
+                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
+                *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
+                w[0] = (int)pack_bf16x2(g1[dt][0], g1[dt][1]);
+                w[1] = (int)pack_bf16x2(g1[dt][2], g1[dt][3]);
+                *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
+            }
+        }
+    }
+
+    // =============================== phase B: queries own, keys stream -> dQ
+    if (orow < N) {
+        bf16x8 y1[2], y2[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { y1[s] = rowfrag(RQ, orow, s, lane); y2[s] = rowfrag(RD, orow, s, lane); }
+        const float ca = row_stat(RQ, orow + li, 0), cb = row_stat(RQ, orow + li, 1);
+        f32x4 g2[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) g2[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (32 * pr >= Nk) break;
+            f32x4 sa[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = 32 * pr + 16 * t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sa[t][r] = row_stat(RK, rb + 4 * g + r, 0);     // key bias of the streamed keys
+                dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RK, rb, s, lane), y1[s], sa[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RV, rb, s, lane), y2[s], dp[t], 0, 0, 0);
+                }
+                mfma_results_ready();
+                const f32x2 la = f32x2{ca, ca}, da = f32x2{cb, cb};
+                const f32x2 ea = pk_fma(lo2(sa[t]), c2, la), eb = pk_fma(hi2(sa[t]), c2, la);
+                const f32x4 pv = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                       __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                const f32x2 ta = pk_fma(lo2(dp[t]), sc2, da), tb = pk_fma(hi2(dp[t]), sc2, da);
+                dp[t] = pv * f32x4{ta[0], ta[1], tb[0], tb[1]};
+            }
+            const bf16x8 dsb = pack_pair(dp[0], dp[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                g2[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RK, 32 * pr, 32 * pr + 16, 16 * dt, lane), dsb, g2[dt], 0, 0, 0);
+        }
+        const int oi = orow + li;
+        if (oi < N) {
+            if (p.rot) {
+                const int hts = p.rot >> 5;
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) {
+                    if (ht >= hts) break;
+                    const int64_t pos = oi + p.qpos;
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cosT + pos * (p.rot >> 1) + 16 * ht + 4 * g);
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sinT + pos * (p.rot >> 1) + 16 * ht + 4 * g);
+                    f32x4& lo = hts == 1 ? g2[0] : g2[ht];
+                    f32x4& hi = hts == 1 ? g2[1] : g2[ht + 2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = lo[r], bb = hi[r];
+                        lo[r] = a * c4[r] + bb * s4[r];
+                        hi[r] = bb * c4[r] - a * s4[r];
+                    }
+                }
+            }
+            bf16_t* dqp = p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
+                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
+                *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
+            }
+        }
+    }
+}
+
 bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off, const void* v,
                   int64_t ldv, int v_off, int64_t ldo, int rot, int B, int H, int Hkv, int Nq, int Nk) {
     if (!q || !k || !v || B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) return false;
@@ -842,6 +1058,15 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
 
+    // one block of queries and keys, one kv head per query head (the DiT's self-attention): everything in one kernel
+    static const bool fused_env = !(getenv("KALLE_ATTN_FUSED_BWD") && atoi(getenv("KALLE_ATTN_FUSED_BWD")) == 0);
+    if (fused_env && !causal && Nq <= 128 && Nk <= 128 && H == Hkv) {
+        constexpr int flds = 4 * AT_TILE;
+        static std::atomic<uint64_t> lds_ok_f{0};
+        kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_fused_kernel), flds, lds_ok_f);
+        KALLE_LAUNCH(attn_bwd_fused_kernel, dim3(1, H, B), dim3(512), flds, st, p);
+        return kalle_check_launch();
+    }
     constexpr int lds = 2 * AT_TILE + 256 * 4;
     static std::atomic<uint64_t> lds_ok_kv{0}, lds_ok_q{0};
     kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_kernel<true, 1>), lds, lds_ok_kv);
