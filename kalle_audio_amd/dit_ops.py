@@ -109,7 +109,8 @@ class GradOut:
 
     def wgrad(self, name, dy, x):
         """dW[N,K] = dy[M,N]^T @ x[M,K]"""
-        if self.deferred is not None and dy.shape[0] % 8 == 0 and dy.is_contiguous() and x.is_contiguous():
+        if (self.deferred is not None and dy.shape[0] % 8 == 0 and dy.stride(-1) == 1 and dy.stride(0) % 8 == 0
+                and dy.data_ptr() % 16 == 0 and x.is_contiguous()):        # (dy may be a column slice: the kernels take ld)
             self.deferred.append((name, dy, x))
             return
         s = self._sink(name)
@@ -226,12 +227,51 @@ def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_at
     return dgrad(dqkv, wqkv)
 
 
-def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None, qkn=None):
-    """transformer.py:411-416, 505-508 (GQA), 541.  h: bf16 [B*N, D]; ctx: bf16 [B*S, Dc]."""
+class ContextKV:
+    """The k | v projections of the conditioning for ALL layers of a ContinuousTransformer in one GEMM: the context is the same
+    tensor for every layer (transformer.py:800-802), only the weights differ - `ctx @ [Wkv_0; Wkv_1; ...]^T` instead of one
+    (tokens x 1536 x 768) GEMM per layer, and on the way back ONE `dctx = dkv_all @ [Wkv_0; ...]` instead of a read-add-store
+    of the fp32 context gradient per layer.  Layer l reads / writes columns [l * 2 Dc, (l + 1) * 2 Dc) in place (the attention
+    kernels take a leading dimension and a column offset)."""
+
+    def __init__(self, ctxb, weights, w_all=None):
+        self.L = len(weights)
+        self.Dc = ctxb.shape[-1]
+        # [L * 2 Dc, Dc] bf16: this forward's weights, kept for the backward (the trainer may update a layer's bf16 mirror
+        # before the context gradient is formed at the end of the backward pass)
+        self.w_all = w_all if w_all is not None else torch.cat(weights, dim=0)
+        self.ld = self.w_all.shape[0]
+        self.kv = ops.gemm(ctxb, self.w_all)                   # [B * S, L * 2 Dc]
+        self.dkv = None
+        self.left = self.L                                     # layers whose backward has not run yet
+
+    def grad_buffer(self):
+        if self.dkv is None:
+            self.dkv = torch.empty_like(self.kv)
+        return self.dkv
+
+    def layer_done(self, want_dctx):
+        """called by every layer's backward after it wrote its dk | dv columns; the last one returns the context gradient"""
+        self.left -= 1
+        if self.left > 0 or not want_dctx:
+            return None
+        return ops.gemm(self.dkv, self.w_all, b_kmajor=True, out_dtype=F32)
+
+
+def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None, qkn=None,
+                   ckv=None, layer_ix=0):
+    """transformer.py:411-416, 505-508 (GQA), 541.  h: bf16 [B*N, D]; ctx: bf16 [B*S, Dc].  ckv: ContextKV of the enclosing
+    ContinuousTransformer (then this layer's k | v are columns of ckv.kv and no projection runs here)."""
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
     q = ops.gemm(h, wq)
+    if ckv is not None and qkn is None:
+        off = layer_ix * 2 * Dc
+        co, lse = ops.attention_fwd(q, ckv.kv, ckv.kv, ldq=D, q_off=0, ldk=ckv.ld, k_off=off, ldv=ckv.ld, v_off=off + Dc,
+                                    B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+        out = ops.gemm(co.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, row_mask=row_mask)
+        return out, (q, (ckv, off), co, lse, None)
     kv = ops.gemm(ctx, wkv)
     nrm = None
     if qkn is not None:
@@ -257,6 +297,15 @@ def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_
     go.wgrad(pre + "to_out.weight", gb, co.view(B * N, D))
     dco = dgrad(gb, wo)
     dq = torch.empty_like(q)
+    if isinstance(kv, tuple):            # k | v live in the ContextKV of the enclosing transformer
+        ckv, off = kv
+        dkv_all = ckv.grad_buffer()
+        ops.attention_bwd(q, ckv.kv, ckv.kv, co, dco, lse, dq, dkv_all, dkv_all, ldq=D, q_off=0, ldk=ckv.ld, k_off=off,
+                          ldv=ckv.ld, v_off=off + Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+        go.wgrad(pre + "to_q.weight", dq, h)
+        dh = dgrad(dq, wq)
+        go.wgrad(pre + "to_kv.weight", dkv_all[:, off:off + 2 * Dc], ctx)
+        return dh, ckv.layer_done(want_dctx)
     dkv = torch.empty_like(kv)
     if nrm is not None:
         qn, qs, kn, ks = nrm
@@ -342,6 +391,7 @@ def block_params(blk):
     if p.ada:
         p.wmod = bf16_of(blk.to_scale_shift_gate[1].weight)
     p.H = blk.dim // blk.dim_heads
+    p.layer_ix = getattr(blk, "layer_ix", 0)
     p.qkn_s = qk_norm_params(blk.self_attn)
     p.qkn_c = qk_norm_params(blk.cross_attn) if p.cross else None
     return p
@@ -356,7 +406,7 @@ BLOCK_PARAM_ORDER = ("pre_norm.gamma", "self_attn.to_qkv.weight", "self_attn.to_
                      "cross_attn.k_norm.bias")
 
 
-def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
+def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S, ckv=None):
     """transformer.py:649-695.  x: fp32 [B*N, D] residual stream; ctx: bf16 [B*S, Dc] or None;
     global_cond: fp32 [B, G] or None (adaLN).  Returns (y fp32 [B*N, D], saved)."""
     D = x.shape[-1]
@@ -377,7 +427,8 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S):
     sv.has_cross = p.cross and ctx is not None
     if sv.has_cross:
         sv.h2, sv.mean2, sv.rstd2 = ops.layernorm_fwd(xcur, p.g2, p.beta2)
-        sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur, qkn=p.qkn_c)
+        sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur, qkn=p.qkn_c,
+                                      ckv=ckv, layer_ix=p.layer_ix)
         xcur = sv.x2
     # feed-forward
     sv.h3, sv.mean3, sv.rstd3 = ops.layernorm_fwd(xcur, p.g3, p.beta3, sc_f, sh_f, rows_per_batch=N)

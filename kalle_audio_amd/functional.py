@@ -294,7 +294,9 @@ class TransformerBlockFn(torch.autograd.Function):
             ctxb = (pre if pre is not None else _to_bf16(context.contiguous())).view(B * S, context.shape[-1])
         gc = _to_f32(global_cond.contiguous()) if global_cond is not None else None
         p = D.block_params(blk)
-        y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S)
+        # k | v of the conditioning already projected for every layer by the enclosing ContinuousTransformer (dit_ops.ContextKV)
+        ckv = getattr(context, "_kalle_ckv", None) if ctxb is not None else None
+        y, sv = D.block_fwd(p, xin, ctxb, gc, mask8, cmask8, rope, B, N, S, ckv=ckv)
         ctx.blk, ctx.sv, ctx.ctxb = blk, sv, ctxb
         blk._kalle_last_rows = B * N                    # (the trainer picks its gradient-clearing rule from it)
         # (the accumulator dict of THIS forward pass: a second forward over the same context tensor gets a new one)

@@ -6,6 +6,8 @@ Not carried over (raise NotImplementedError when requested): causal attention, n
 attention, conv feed-forward, ConformerModule, sinusoidal/absolute position embeddings - none is reachable from
 the DiT path (dit.py:107-125) with the configs the reference ships.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -215,6 +217,36 @@ class ContinuousTransformer(nn.Module):
                                                 causal=causal, zero_init_branch_outputs=zero_init_branch_outputs,
                                                 conformer=conformer, layer_ix=i, **kwargs))
 
+    def _project_context_for_all_layers(self, context):
+        """the conditioning is one tensor for every layer: its k | v projections for all of them in ONE GEMM (dit_ops.ContextKV,
+        hung on the context tensor for the layers to find); KALLE_BATCH_CTX_KV=0 keeps one projection per layer"""
+        if context is None or os.environ.get("KALLE_BATCH_CTX_KV", "1") == "0" or len(self.layers) < 2:
+            return
+        layers = list(self.layers)
+        if not all(l.cross_attend and l.cross_attn.qk_norm == "none" for l in layers):
+            return
+        dc = layers[0].cross_attn.to_kv.weight.shape[1]
+        if context.shape[-1] != dc or any(l.cross_attn.to_kv.weight.shape != layers[0].cross_attn.to_kv.weight.shape for l in layers):
+            return
+        pre = getattr(context, "_kalle_bf16", None)
+        ctxb = (pre if pre is not None else KF._to_bf16(context.contiguous())).view(-1, dc)
+        ws = [l.cross_attn.to_kv.weight for l in layers]
+        w_all = None
+        frozen = not torch.is_grad_enabled() and all(getattr(w, "_kalle_bf16_pinned", None) is None for w in ws)
+        if frozen:      # inference: the stacked weights are rebuilt only when a parameter changed (sampler loops call this per step)
+            key = tuple(w._version for w in ws) + (ws[0].device,)
+            hit = getattr(self, "_kalle_wall", None)
+            if hit is not None and hit[0] == key:
+                w_all = hit[1]
+        bw = [KF.D.bf16_of(w) for w in ws]
+        ckv = KF.D.ContextKV(ctxb, bw, w_all)
+        if frozen and w_all is None:
+            object.__setattr__(self, "_kalle_wall", (key, ckv.w_all))
+        try:
+            context._kalle_ckv = ckv
+        except (AttributeError, RuntimeError):
+            pass
+
     def forward(self, x, mask=None, prepend_embeds=None, prepend_mask=None, global_cond=None, return_info=False,
                 **kwargs):
         _need_gpu(x)
@@ -250,6 +282,7 @@ class ContinuousTransformer(nn.Module):
             gated._kalle_bf16 = KF._to_bf16(ctx.detach().contiguous())
             gated._kalle_dctx = {}
             kwargs = dict(kwargs, context=gated)
+        self._project_context_for_all_layers(kwargs.get("context"))
         for layer in self.layers:
             x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
             if return_info:

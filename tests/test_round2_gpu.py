@@ -1154,3 +1154,27 @@ def test_attention_random_lengths_and_groups(dev):
         ops.attention_bwd(q, kv, kv, out, dout, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc,
                           B=B, H=H, Hkv=Hkv, Nq=Nq, Nk=Nk, key_mask=mask)
         assert rel(dq, qr.grad) < 2e-2 and rel(dkv, kvr.grad) < 2e-2, (it, Nq, Nk, H, Hkv, rel(dq, qr.grad), rel(dkv, kvr.grad))
+
+
+def test_batched_context_projection_equals_per_layer(dev, monkeypatch):
+    """the k | v projections of the conditioning for all layers in one GEMM (dit_ops.ContextKV: strided k / v columns into the
+    attention kernels, dk | dv written in place, ONE context-gradient GEMM at the end of the backward pass) against one projection
+    per layer: same output, same parameter gradients, same context gradient up to the order of the fp32 sum over layers"""
+    from stable_audio_tools.models.transformer import ContinuousTransformer
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("KALLE_BATCH_CTX_KV", mode)
+        ct = load_seeded(ContinuousTransformer(D, 3, dim_heads=64, cross_attend=True, cond_token_dim=DC, global_cond_dim=None), 91, dev)
+        x = T(gu.make_input("x", (2, 40, D), 91), dev, True)
+        ctx = T(gu.make_input("ctx", (2, 24, DC), 91), dev, True)
+        cm = (torch.arange(24)[None, :] < torch.tensor([24, 17])[:, None]).to(dev)
+        y = ct(x, context=ctx, context_mask=cm)
+        y.backward(T(gu.make_input("dy", (2, 40, D), 91), dev))
+        res[mode] = (y.detach().clone(), x.grad.clone(), ctx.grad.clone(), {n: p.grad.clone() for n, p in ct.named_parameters()})
+        with torch.no_grad():
+            res[mode + "i"] = ct(x.detach(), context=ctx.detach(), context_mask=cm)
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(res["1i"], res["0i"]) and torch.equal(a[0], res["1i"])
+    assert rel(a[1], b[1]) < 1e-6 and rel(a[2], b[2]) < 1e-5, (rel(a[1], b[1]), rel(a[2], b[2]))
+    for n in a[3]:
+        assert rel(a[3][n], b[3][n]) < 1e-5, (n, rel(a[3][n], b[3][n]))
