@@ -1,4 +1,7 @@
-# knock-out timing of the skinny kernels (rocprofv3 kernel durations). dbg bits: 1 no stores, 2 no pipeline, 4 no MFMAs, 8 no in-loop DMA
+# knock-out timing of the few-row GEMM kernels (rocprofv3 kernel durations). dbg bits: 1 no stores, 2 no pipeline, 4 no MFMAs, 8 no in-loop DMA.
+# The `GemmParams.dbg` switches this script drives (KALLE_FEW_ROWS_DBG) were taken out of the shipped kernels again once the numbers in
+# DESIGN.md section 5.0 were recorded (they cost a branch per MFMA block); `git log -S'KALLE_FEW_ROWS_DBG' -- kalle_audio_amd/csrc/gemm2.hip`
+# finds the commits that carry them.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r02ko; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
