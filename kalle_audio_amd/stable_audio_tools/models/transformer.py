@@ -283,10 +283,17 @@ class ContinuousTransformer(nn.Module):
             gated._kalle_dctx = {}
             kwargs = dict(kwargs, context=gated)
         self._project_context_for_all_layers(kwargs.get("context"))
-        for layer in self.layers:
-            x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
-            if return_info:
-                info["hidden_states"].append(x)
+        try:
+            for layer in self.layers:
+                x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)
+                if return_info:
+                    info["hidden_states"].append(x)
+        finally:
+            # the stacked projections belong to THIS forward of THIS transformer (the backward holds its own reference): a later
+            # call with the same context tensor - another model, a block on its own, updated weights - must not find them
+            c = kwargs.get("context")
+            if c is not None and hasattr(c, "_kalle_ckv"):
+                del c._kalle_ckv
         if isinstance(self.project_out, nn.Linear):
             x = KF.linear(x, self.project_out.weight, out_dtype=torch.float32)
         if return_info:

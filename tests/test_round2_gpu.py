@@ -1173,6 +1173,10 @@ def test_batched_context_projection_equals_per_layer(dev, monkeypatch):
         res[mode] = (y.detach().clone(), x.grad.clone(), ctx.grad.clone(), {n: p.grad.clone() for n, p in ct.named_parameters()})
         with torch.no_grad():
             res[mode + "i"] = ct(x.detach(), context=ctx.detach(), context_mask=cm)
+        if mode == "1":     # the stacked projections do not outlive the forward that made them
+            assert not hasattr(ctx, "_kalle_ckv")
+            blk_alone = ct.layers[1](x.detach(), context=ctx.detach(), context_mask=cm)
+            assert torch.isfinite(blk_alone).all()
     a, b = res["1"], res["0"]
     assert torch.equal(a[0], b[0]) and torch.equal(res["1i"], res["0i"]) and torch.equal(a[0], res["1i"])
     assert rel(a[1], b[1]) < 1e-6 and rel(a[2], b[2]) < 1e-5, (rel(a[1], b[1]), rel(a[2], b[2]))
