@@ -236,7 +236,8 @@ int kalle_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n
 /* residual-stream gradient -> bf16 GEMM operand, with the adaLN gate backward fused in:
  *   gb[b,t,n]   = bf16( g[b,t,n] * (gate ? sigmoid(1-gate[b,n]) : 1) * (row_mask ? row_mask[b*T+t] : 1) )
  *   dgate[b,n]  = -(1 - sigmoid(1-gate[b,n])) * sum_t g[b,t,n]*row_mask * (x_out[b,t,n] - x_in[b,t,n])     (gate != NULL)
- * (x_out = x_in + branch*sigmoid(1-gate), transformer.py:667-668,681-682; x_out/x_in/dgate unused when gate == NULL) */
+ * (x_out = x_in + branch*sigmoid(1-gate), transformer.py:667-668,681-682; x_out/x_in/dgate unused when gate == NULL).
+ * D % 4 == 0, ldg % 4 == 0, 16-byte aligned rows; dgate is cleared and then summed atomically over chunks of rows. */
 int kalle_grad_cast(const float* g, const float* x_out, const float* x_in, const float* gate, int64_t ldg,
                     const uint8_t* row_mask, void* gb, float* dgate, int nbatch, int rows_per_batch, int D,
                     void* stream);

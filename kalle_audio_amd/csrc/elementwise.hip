@@ -298,37 +298,48 @@ __global__ void fourier_kernel(const float* __restrict__ t, const float* __restr
     }
 }
 
-// ---- residual gradient -> bf16 operand (+ adaLN gate backward); one thread per (batch, column pair) ------
-__global__ __launch_bounds__(256) void grad_cast_kernel(const float* __restrict__ g, const float* __restrict__ xo,
+// ---- residual gradient -> bf16 operand (+ adaLN gate backward) -------------------------------------------------------------
+// A thread owns 4 columns (16-byte loads of g / x_out / x_in, one 8-byte store) of a chunk of `rpc` rows of one batch element;
+// the gate gradient is a sum over the element's rows: per-chunk partial sums are added atomically into the zeroed dgate
+// (8 adds per value at 126 rows) - the one-thread-per-column-pair form walked all rows serially with 8-byte loads on 12 waves per
+// CU and reached 2.4 TB/s of the 14 bytes per element it moves.
+__global__ __launch_bounds__(128) void grad_cast_kernel(const float* __restrict__ g, const float* __restrict__ xo,
                                                         const float* __restrict__ xi, const float* __restrict__ gate,
                                                         int64_t ldg, const uint8_t* __restrict__ rmask,
                                                         bf16_t* __restrict__ gb, float* __restrict__ dgate, int rpb,
-                                                        int D) {
-    const int b = blockIdx.y;
-    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+                                                        int D, int rpc) {
+    const int b = blockIdx.z;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (col >= D) return;
-    float s0 = 1.f, s1 = 1.f;
+    const int t0 = blockIdx.y * rpc, t1 = min(t0 + rpc, rpb);
+    float s[4] = {1.f, 1.f, 1.f, 1.f};
     if (gate) {
-        s0 = sigmoidf_(1.f - gate[(int64_t)b * ldg + col]);
-        s1 = sigmoidf_(1.f - gate[(int64_t)b * ldg + col + 1]);
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (int64_t)b * ldg + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = sigmoidf_(1.f - gt[j]);
     }
-    float a0 = 0.f, a1 = 0.f;
-    for (int t = 0; t < rpb; ++t) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int t = t0; t < t1; ++t) {
         const int64_t row = (int64_t)b * rpb + t;
         const float m = (rmask && !rmask[row]) ? 0.f : 1.f;
-        const f32x2 gv = *reinterpret_cast<const f32x2*>(g + row * D + col);
-        const float g0 = gv[0] * m, g1 = gv[1] * m;
+        f32x4 gv = *reinterpret_cast<const f32x4*>(g + row * D + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[j] *= m;
         if (gate) {
-            const f32x2 o = *reinterpret_cast<const f32x2*>(xo + row * D + col);
-            const f32x2 i = *reinterpret_cast<const f32x2*>(xi + row * D + col);
-            a0 += g0 * (o[0] - i[0]);
-            a1 += g1 * (o[1] - i[1]);
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xo + row * D + col);
+            const f32x4 i = *reinterpret_cast<const f32x4*>(xi + row * D + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += gv[j] * (o[j] - i[j]);
         }
-        *reinterpret_cast<uint32_t*>(gb + row * D + col) = pack_bf16x2(g0 * s0, g1 * s1);
+        i32x2 w;
+        w[0] = (int)pack_bf16x2(gv[0] * s[0], gv[1] * s[1]);
+        w[1] = (int)pack_bf16x2(gv[2] * s[2], gv[3] * s[3]);
+        *reinterpret_cast<i32x2*>(gb + row * D + col) = w;
     }
     if (gate && dgate) {
-        dgate[(int64_t)b * ldg + col] = -(1.f - s0) * a0;
-        dgate[(int64_t)b * ldg + col + 1] = -(1.f - s1) * a1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dgate + (int64_t)b * ldg + col + j, -(1.f - s[j]) * a[j]);
     }
 }
 
@@ -501,11 +512,18 @@ extern "C" int kalle_fourier_features(const float* t, const float* w, void* out,
 extern "C" int kalle_grad_cast(const float* g, const float* x_out, const float* x_in, const float* gate, int64_t ldg,
                                const uint8_t* row_mask, void* gb, float* dgate, int nbatch, int rows_per_batch, int D,
                                void* stream) {
-    if (!g || !gb || nbatch <= 0 || rows_per_batch <= 0 || D <= 0 || (D & 1) || nbatch > 65535) return KALLE_ERR_ARG;
-    if (gate && (!x_out || !x_in)) return KALLE_ERR_ARG;
-    dim3 block(128), grid((D / 2 + 127) / 128, nbatch);
-    KALLE_LAUNCH(grad_cast_kernel, grid, block, 0, static_cast<hipStream_t>(stream), g, x_out, x_in, gate, ldg,
-                       row_mask, static_cast<bf16_t*>(gb), dgate, rows_per_batch, D);
+    if (!g || !gb || nbatch <= 0 || rows_per_batch <= 0 || D <= 0 || (D & 3) || nbatch > 65535) return KALLE_ERR_ARG;
+    if (gate && (!x_out || !x_in || (ldg & 3))) return KALLE_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (gate && dgate) {        // the kernel adds per-chunk partial sums
+        if (hipMemset2DAsync(dgate, sizeof(float) * ldg, 0, sizeof(float) * D, nbatch, st) != hipSuccess) return KALLE_ERR_LAUNCH;
+    }
+    const int rpc = 16;
+    const int chunks = (rows_per_batch + rpc - 1) / rpc;
+    if (chunks > 65535) return KALLE_ERR_ARG;
+    dim3 block(128), grid((D / 4 + 127) / 128, chunks, nbatch);
+    KALLE_LAUNCH(grad_cast_kernel, grid, block, 0, st, g, x_out, x_in, gate, ldg,
+                       row_mask, static_cast<bf16_t*>(gb), dgate, rows_per_batch, D, rpc);
     return kalle_check_launch();
 }
 extern "C" int kalle_fourier_features_bwd(const float* dout, const float* t, const float* w, float* dw, int nbatch,

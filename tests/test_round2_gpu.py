@@ -1182,3 +1182,26 @@ def test_batched_context_projection_equals_per_layer(dev, monkeypatch):
     assert rel(a[1], b[1]) < 1e-6 and rel(a[2], b[2]) < 1e-5, (rel(a[1], b[1]), rel(a[2], b[2]))
     for n in a[3]:
         assert rel(a[3][n], b[3][n]) < 1e-5, (n, rel(a[3][n], b[3][n]))
+
+
+@pytest.mark.parametrize("B,N,Dm", [(3, 126, 1536), (2, 7, 128), (1, 40, 260)])
+def test_grad_cast_gate_backward_vs_torch(dev, B, N, Dm):
+    """kalle_grad_cast: bf16 GEMM operand of the residual-stream gradient with the adaLN gate backward
+    (transformer.py:667-668, 681-682: x_out = x_in + branch * sigmoid(1 - gate)), row mask, chunked row sums"""
+    from kalle_audio_amd import ops
+    g_ = torch.Generator().manual_seed(B * 1000 + N)
+    g = torch.randn(B * N, Dm, generator=g_).to(dev)
+    xi = torch.randn(B * N, Dm, generator=g_).to(dev)
+    br = torch.randn(B * N, Dm, generator=g_).to(dev)
+    gate = torch.randn(B, Dm, generator=g_).to(dev)
+    sg = torch.sigmoid(1 - gate)
+    xo = xi + br * sg.repeat_interleave(N, 0)
+    mask = (torch.rand(B * N, generator=g_) > 0.2).to(dev)
+    for rm in (None, mask):
+        gm = g if rm is None else g * rm[:, None].float()
+        gb, dg = ops.grad_cast(g, B, N, gate=gate, x_out=xo, x_in=xi, row_mask=rm)
+        want_gb = gm * sg.repeat_interleave(N, 0)
+        want_dg = -(1 - sg) * (gm * (xo - xi)).view(B, N, Dm).sum(1)
+        assert rel(gb, want_gb) < 4e-3 and rel(dg, want_dg) < 1e-5, (rel(gb, want_gb), rel(dg, want_dg))
+    gb, dg = ops.grad_cast(g, B, N, row_mask=mask)
+    assert dg is None and rel(gb, g * mask[:, None].float()) < 4e-3
