@@ -870,6 +870,285 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
     }
 }
 
+// ---- the same for the DiT's cross-attention: `group` query heads per kv head and a few keys beyond the 128-row block --------------
+// One workgroup per (batch, kv head).  Pass-major, so that no accumulator outlives its pass (128 VGPRs keep two workgroups on a CU):
+//   pass A: for every head of the group stage Q, dO and accumulate dK, dV of keys 0..127; store them;
+//   pass B: for every head (last-staged first) dQ over all keys; store it.
+// Keys 128 .. Nk-1 (the 130-token context of the bench has two) ride in the rows of the Q / dO tiles that the <= 126 queries leave
+// free: as a ninth streamed key tile in pass B (rows 112..127 of the Q / dO images, the queries among them masked by a key bias
+// of -inf) and, for their own dK / dV, as a ninth owner tile that wave 7 walks after its pass-B work.  No rotary here (the
+// cross-attention has none); K / V of a head group are read once, Q / dO of the first head twice (second time from L2).
+__global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p) {
+    constexpr int NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* RQ = smem;                  // pad slots: 0 = -lse * log2 e (query role), 1 = -delta * scale, 2 = key bias (key role, rows >= 112)
+    char* RD = smem + AT_TILE;
+    char* RK = smem + 2 * AT_TILE;    // pad slot 0: key bias of keys 0..127
+    char* RV = smem + 3 * AT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.z, hk = blockIdx.y;
+    const int group = p.H / p.Hkv;
+    const int N = p.Nq, Nk = p.Nk;
+    const int nmain = min(Nk, 128), tail = Nk - nmain;        // tail keys live in rows [128 - tail, 128) of RQ / RD
+    const int trow0 = 128 - tail;
+    const bf16_t* kb = p.k + (int64_t)b * Nk * p.ldk + p.k_off + hk * 64;
+    const bf16_t* vb = p.v + (int64_t)b * Nk * p.ldv + p.v_off + hk * 64;
+    const f32x2 c2 = f32x2{SM_SCALE_LOG2E, SM_SCALE_LOG2E}, sc2 = f32x2{SM_SCALE, SM_SCALE};
+    const int orow = wave * 16;
+    const int drow = tid >> 2, dq4 = tid & 3;
+
+    // ---- stage Q, dO of head h (+ the tail keys into the free rows, + per-row statistics); K, V with the first head
+    auto stage_head = [&](int h, bool with_kv, bool write_delta) {
+        const bf16_t* qb = p.q + (int64_t)b * N * p.ldq + p.q_off + h * 64;
+        const bf16_t* dob = p.dout + (int64_t)b * N * p.ldo + h * 64;
+        TileRegs<NT> tq, td, tk, tv;
+        tile_load<NT>(tq, qb, p.ldq, 0, N, 0, tid);
+        tile_load<NT>(td, dob, p.ldo, 0, N, 0, tid);
+        if (with_kv) {
+            tile_load<NT>(tk, kb, p.ldk, 0, nmain, 0, tid);
+            tile_load<NT>(tv, vb, p.ldv, 0, nmain, 0, tid);
+        }
+        i32x4 o0v = i32x4{0, 0, 0, 0}, o1v = i32x4{0, 0, 0, 0};
+        if (drow < N) {
+            const bf16_t* op = p.out + ((int64_t)b * N + drow) * p.ldo + h * 64 + 16 * dq4;
+            o0v = *reinterpret_cast<const i32x4*>(op);
+            o1v = *reinterpret_cast<const i32x4*>(op + 8);
+        }
+        i32x4 tkv = i32x4{0, 0, 0, 0}, tvv = i32x4{0, 0, 0, 0};      // tail keys: 8 threads x 16 bytes per row
+        const int tj = tid >> 3, tc = tid & 7;
+        if (tj < tail) {
+            tkv = *reinterpret_cast<const i32x4*>(kb + (int64_t)(128 + tj) * p.ldk + 8 * tc);
+            tvv = *reinterpret_cast<const i32x4*>(vb + (int64_t)(128 + tj) * p.ldv + 8 * tc);
+        }
+        tile_store<NT>(RQ, tq, 0, N, nullptr, nullptr, 0, tid);
+        tile_store<NT>(RD, td, 0, N, nullptr, nullptr, 0, tid);
+        if (with_kv) {
+            tile_store<NT>(RK, tk, 0, nmain, nullptr, nullptr, 0, tid);
+            tile_store<NT>(RV, tv, 0, nmain, nullptr, nullptr, 0, tid);
+        }
+        __syncthreads();
+        if (tj < tail) {
+            *reinterpret_cast<i32x4*>(RQ + (trow0 + tj) * AT_STRIDE + 16 * tc) = tkv;
+            *reinterpret_cast<i32x4*>(RD + (trow0 + tj) * AT_STRIDE + 16 * tc) = tvv;
+        }
+        const i32x4 d0v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4);
+        const i32x4 d1v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4 + 16);
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dl += bf16lo((uint32_t)o0v[e]) * bf16lo((uint32_t)d0v[e]) + bf16hi((uint32_t)o0v[e]) * bf16hi((uint32_t)d0v[e]);
+            dl += bf16lo((uint32_t)o1v[e]) * bf16lo((uint32_t)d1v[e]) + bf16hi((uint32_t)o1v[e]) * bf16hi((uint32_t)d1v[e]);
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        dl += __shfl_xor(dl, 2, 64);
+        if (dq4 == 0) {
+            const bool ok = drow < N;
+            row_stat(RQ, drow, 0) = ok ? -p.lse[((int64_t)b * p.H + h) * N + drow] * LOG2E : -INFINITY;
+            row_stat(RQ, drow, 1) = ok ? -dl * SM_SCALE : 0.f;
+            if (ok && write_delta) p.delta[((int64_t)b * p.H + h) * N + drow] = dl;
+        } else if (dq4 == 1) {
+            bool ok = drow >= trow0;                                   // this row holds tail key 128 + (drow - trow0)
+            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + 128 + (drow - trow0)] != 0;
+            row_stat(RQ, drow, 2) = ok ? 0.f : -INFINITY;
+        } else if (dq4 == 2 && with_kv) {
+            bool ok = drow < nmain;
+            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + drow] != 0;
+            row_stat(RK, drow, 0) = ok ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+    };
+
+    // ---- keys own (fragments y1 / y2 of 16 key rows, bias ca), the queries of the staged head stream: dK^T, dV^T +=
+    auto keys_own = [&](const bf16x8 (&y1)[2], const bf16x8 (&y2)[2], float ca, f32x4 (&gv)[4], f32x4 (&gk)[4]) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (32 * pr >= N) break;
+            f32x4 sa[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int rb = 32 * pr + 16 * t;
+                sa[t] = f32x4{ca, ca, ca, ca};
+                dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RQ, rb, s, lane), y1[s], sa[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(RD, rb, s, lane), y2[s], dp[t], 0, 0, 0);
+                }
+                f32x4 ra, rbv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ra[r] = row_stat(RQ, rb + 4 * g + r, 0); rbv[r] = row_stat(RQ, rb + 4 * g + r, 1); }
+                mfma_results_ready();
+                const f32x2 ea = pk_fma(lo2(sa[t]), c2, lo2(ra)), eb = pk_fma(hi2(sa[t]), c2, hi2(ra));
+                f32x4 pv = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                 __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                const f32x2 ta = pk_fma(lo2(dp[t]), sc2, lo2(rbv)), tb = pk_fma(hi2(dp[t]), sc2, hi2(rbv));
+                f32x4 ds = pv * f32x4{ta[0], ta[1], tb[0], tb[1]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {            // rows past the queries hold tail keys, not dO: their dP is not a number to keep
+                    if (rb + 4 * g + r >= N) { pv[r] = 0.f; ds[r] = 0.f; }
+                }
+                sa[t] = pv;
+                dp[t] = ds;
+            }
+            const bf16x8 pb = pack_pair(sa[0], sa[1]), dsb = pack_pair(dp[0], dp[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                gk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RQ, 32 * pr, 32 * pr + 16, 16 * dt, lane), dsb, gk[dt], 0, 0, 0);
+                gv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RD, 32 * pr, 32 * pr + 16, 16 * dt, lane), pb, gv[dt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ================================= pass A: dK, dV of keys 0..127, summed over the heads of the group
+    {
+        stage_head(hk * group, true, true);       // (before the accumulators exist: its 48 registers of loads in flight are not theirs)
+        f32x4 g1[4], g2[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { g1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; g2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int hh = 0; hh < group; ++hh) {
+            if (hh > 0) {
+                __syncthreads();
+                stage_head(hk * group + hh, false, true);
+            }
+            if (orow < nmain) {
+                bf16x8 y1[2], y2[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { y1[s] = rowfrag(RK, orow, s, lane); y2[s] = rowfrag(RV, orow, s, lane); }
+                keys_own(y1, y2, row_stat(RK, orow + li, 0), g1, g2);
+            }
+        }
+        const int oi = orow + li;
+        if (oi < nmain) {
+            bf16_t* dkp = p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + hk * 64 + 4 * g;
+            bf16_t* dvp = p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + hk * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                i32x2 w;
+                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
+                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
+                *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
+                w[0] = (int)pack_bf16x2(g1[dt][0], g1[dt][1]);
+                w[1] = (int)pack_bf16x2(g1[dt][2], g1[dt][3]);
+                *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
+            }
+        }
+    }
+
+    // ================================= pass B: dQ of every head (the last-staged one first); wave 7 also gathers dK, dV of the tail keys
+    for (int hh = group - 1; hh >= 0; --hh) {
+        const int h = hk * group + hh;
+        if (hh != group - 1) {
+            __syncthreads();
+            stage_head(h, false, false);
+        }
+        if (orow < N) {
+            bf16x8 y1[2], y2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { y1[s] = rowfrag(RQ, orow, s, lane); y2[s] = rowfrag(RD, orow, s, lane); }
+            const float ca = row_stat(RQ, orow + li, 0), cb = row_stat(RQ, orow + li, 1);
+            f32x4 gq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) gq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // streamed key tiles: pairs 0..3 from RK / RV, then (tail keys) rows 112..127 of RQ / RD paired with nothing
+            auto stream_keys = [&](const char* SK, const char* SV, int base, auto ext_c) {
+                constexpr bool EXT = decltype(ext_c)::value;
+                f32x4 dp[2];
+#pragma unroll
+                for (int t = 0; t < (EXT ? 1 : 2); ++t) {
+                    dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int rb = base + 16 * t;
+                    f32x4 sa;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sa[r] = EXT ? row_stat(RQ, rb + 4 * g + r, 2) : row_stat(RK, rb + 4 * g + r, 0);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(SK, rb, s, lane), y1[s], sa, 0, 0, 0);
+                        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag(SV, rb, s, lane), y2[s], dp[t], 0, 0, 0);
+                    }
+                    mfma_results_ready();
+                    const f32x2 la = f32x2{ca, ca}, da = f32x2{cb, cb};
+                    const f32x2 ea = pk_fma(lo2(sa), c2, la), eb = pk_fma(hi2(sa), c2, la);
+                    const f32x4 pv = f32x4{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1]),
+                                           __builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+                    const f32x2 ta = pk_fma(lo2(dp[t]), sc2, da), tb = pk_fma(hi2(dp[t]), sc2, da);
+                    f32x4 ds = pv * f32x4{ta[0], ta[1], tb[0], tb[1]};
+                    if constexpr (EXT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (rb + 4 * g + r < trow0) ds[r] = 0.f;      // a query row in the key role: P is 0, dP is not a number to keep
+                    }
+                    dp[t] = ds;
+                }
+                if constexpr (EXT) dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bf16x8 dsb = pack_pair(dp[0], dp[1]);
+                const int rb_ = EXT ? base : base + 16;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    gq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(SK, base, rb_, 16 * dt, lane), dsb, gq[dt], 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int pr = 0; pr < 4; ++pr) {
+                if (32 * pr >= nmain) break;
+                stream_keys(RK, RV, 32 * pr, std::false_type{});
+            }
+            if (tail > 0) stream_keys(RQ, RD, 112, std::true_type{});
+            const int oi = orow + li;
+            if (oi < N) {
+                bf16_t* dqp = p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    i32x2 w;
+                    w[0] = (int)pack_bf16x2(gq[dt][0], gq[dt][1]);
+                    w[1] = (int)pack_bf16x2(gq[dt][2], gq[dt][3]);
+                    *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
+                }
+            }
+        }
+        if (tail > 0 && wave == 7) {        // the ninth owner tile: rows 112..127 of the Q / dO images in the key role
+            // its accumulators rest between heads in the pad bytes of the dO / V tile rows 2 * lane, 2 * lane + 1 (staging writes only
+            // the first 128 bytes of a row): held in registers across the dQ work above they cost 20 spilled VGPRs
+            f32x4 gt1[4], gt2[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                if (hh == group - 1) { gt1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; gt2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                else {
+                    gt1[dt] = *reinterpret_cast<const f32x4*>(RD + (2 * lane + (dt >> 1)) * AT_STRIDE + 128 + 16 * (dt & 1));
+                    gt2[dt] = *reinterpret_cast<const f32x4*>(RV + (2 * lane + (dt >> 1)) * AT_STRIDE + 128 + 16 * (dt & 1));
+                }
+            }
+            bf16x8 y1[2], y2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { y1[s] = rowfrag(RQ, 112, s, lane); y2[s] = rowfrag(RD, 112, s, lane); }
+            keys_own(y1, y2, row_stat(RQ, 112 + li, 2), gt1, gt2);
+            if (hh > 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<f32x4*>(RD + (2 * lane + (dt >> 1)) * AT_STRIDE + 128 + 16 * (dt & 1)) = gt1[dt];
+                    *reinterpret_cast<f32x4*>(RV + (2 * lane + (dt >> 1)) * AT_STRIDE + 128 + 16 * (dt & 1)) = gt2[dt];
+                }
+            } else {
+                const int row = 112 + li;
+                if (row >= trow0) {
+                    const int key = 128 + (row - trow0);
+                    bf16_t* dkp = p.dk + ((int64_t)b * Nk + key) * p.ldk + p.k_off + hk * 64 + 4 * g;
+                    bf16_t* dvp = p.dv + ((int64_t)b * Nk + key) * p.ldv + p.v_off + hk * 64 + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        i32x2 w;
+                        w[0] = (int)pack_bf16x2(gt2[dt][0], gt2[dt][1]);
+                        w[1] = (int)pack_bf16x2(gt2[dt][2], gt2[dt][3]);
+                        *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
+                        w[0] = (int)pack_bf16x2(gt1[dt][0], gt1[dt][1]);
+                        w[1] = (int)pack_bf16x2(gt1[dt][2], gt1[dt][3]);
+                        *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
+                    }
+                }
+            }
+        }
+    }
+}
+
 bool check_common(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off, const void* v,
                   int64_t ldv, int v_off, int64_t ldo, int rot, int B, int H, int Hkv, int Nq, int Nk) {
     if (!q || !k || !v || B <= 0 || H <= 0 || Hkv <= 0 || Nq <= 0 || Nk <= 0) return false;
@@ -1065,6 +1344,16 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
         static std::atomic<uint64_t> lds_ok_f{0};
         kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_fused_kernel), flds, lds_ok_f);
         KALLE_LAUNCH(attn_bwd_fused_kernel, dim3(1, H, B), dim3(512), flds, st, p);
+        return kalle_check_launch();
+    }
+    // cross-attention of the DiT: several query heads per kv head and / or a few keys beyond one block, no rotary
+    static const bool gqa_env = !(getenv("KALLE_ATTN_FUSED_GQA") && atoi(getenv("KALLE_ATTN_FUSED_GQA")) == 0);
+    const int tail = Nk > 128 ? Nk - 128 : 0;
+    if (fused_env && gqa_env && !causal && rot == 0 && Nq <= 128 && tail <= 16 && tail <= 128 - Nq) {
+        constexpr int flds = 4 * AT_TILE;
+        static std::atomic<uint64_t> lds_ok_g{0};
+        kalle_allow_lds(reinterpret_cast<const void*>(attn_bwd_fused_gqa_kernel), flds, lds_ok_g);
+        KALLE_LAUNCH(attn_bwd_fused_gqa_kernel, dim3(1, Hkv, B), dim3(512), flds, st, p);
         return kalle_check_launch();
     }
     constexpr int lds = 2 * AT_TILE + 256 * 4;

@@ -1130,11 +1130,17 @@ def test_attention_random_lengths_and_groups(dev):
     from kalle_audio_amd import ops
     from test_kernels_gpu import _attn_ref, _mk
     rng = np.random.RandomState(5)
-    for it in range(14):
+    # (explicit cases for the fused backward with tail keys in the free rows of the query tiles: full tail of 16, tail keys masked,
+    # group of 4, fewer than 112 queries)
+    explicit = [(112, 144, 2, 4), (126, 130, 1, 4), (100, 140, 2, 2), (126, 129, 2, 2), (97, 128, 1, 2), (128, 128, 2, 4)]
+    for it in range(14 + len(explicit)):
         Nq = int(rng.choice([1, 15, 126, 128, 129, 257, 300]))
         Nk = int(rng.choice([2, 17, 127, 128, 130, 256, 259]))
         Hkv = int(rng.choice([1, 2]))
         H = Hkv * int(rng.choice([1, 2, 4]))
+        if it >= 14:
+            Nq, Nk, Hkv, grp = explicit[it - 14]
+            H = Hkv * grp
         B, D, Dc = 2, H * 64, Hkv * 64
         q = (_mk((B, Nq, D), dev, seed=300 + it) * 0.8).bfloat16()
         kv = (_mk((B, Nk, 2 * Dc), dev, seed=400 + it) * 0.8).bfloat16()
@@ -1143,6 +1149,8 @@ def test_attention_random_lengths_and_groups(dev):
         if it % 2:
             mask = torch.rand(B, Nk, device=dev) > 0.3
             mask[:, 0] = True
+            if it >= 14 and Nk > 128:
+                mask[0, 128:] = False            # every tail key of the first clip masked
         qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
         k, v = kvr.chunk(2, -1)
         ref = _attn_ref(qr, k, v, mask, None, H, Hkv)
