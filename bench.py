@@ -58,11 +58,12 @@ def build_model(device, seed=1234, cfg=CFG):
                                             cross_attn_cond_ids=["prompt"], global_cond_ids=["global"])
 
 
-def make_batch(B, device, seed, cfg=CFG):
+def make_batch(B, device, seed, cfg=CFG, T=None):
+    T = T_FRAMES if T is None else T
     g = torch.Generator(device=device).manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g, device=device)
-    lat = r(B, cfg["io_channels"], T_FRAMES)
-    noise = r(B, cfg["io_channels"], T_FRAMES)
+    lat = r(B, cfg["io_channels"], T)
+    noise = r(B, cfg["io_channels"], T)
     t = torch.rand(B, generator=g, device=device)
     cond = {"prompt": (r(B, S_CTX, cfg["cond_token_dim"]), torch.ones(B, S_CTX, dtype=torch.bool, device=device)),
             "global": (r(B, cfg["global_cond_dim"]), None)}
@@ -211,14 +212,23 @@ def main():
             dom = max(agg.items(), key=lambda kv: kv[1][1])
             name, (fl, sec, n, ab) = dom
             ach = fl / sec / 1e12
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "traffic_r02.json")
-            if not os.path.exists(tj):
-                tj = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tj):
-                traffic = json.load(open(tj)).get(name)
+            # HBM-side bytes per launch of this kernel from the committed PMC passes (profiles/traffic_rNN.json, newest round;
+            # tools/pmc_traffic_summary.py) - counters cannot be read inside this process, so the line says where the number
+            # comes from: the kernel-source hash of the profiled build, the commit, and whether the running tree still matches
+            traffic = traffic_source = None
+            import glob
+            tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r[0-9][0-9].json")))
+            if tjs:
+                tjd = json.load(open(tjs[-1]))
+                traffic = tjd.get(name)
+                from kalle_audio_amd.build import source_stamp
+                src = tjd.get("_source") or {}
+                traffic_source = {"file": os.path.relpath(tjs[-1], ROOT), "csrc_sha16": src.get("csrc_sha16"),
+                                  "commit": src.get("commit_at_publish"),
+                                  "matches_running_code": src.get("csrc_sha16") == source_stamp()}
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                               "traffic_source": traffic_source,
                                "launches": n, "avg_launch_us": sec / n * 1e6, "avg_flop_per_launch": fl / n,
                                "algorithmic_bytes_per_launch": ab / n,
                                "all_gemm_variants": {k: {"tflops": v[0] / v[1] / 1e12, "avg_us": v[1] / v[2] * 1e6,

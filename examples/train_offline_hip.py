@@ -91,7 +91,7 @@ def main():
 
     total = int(config.get("total_steps", 10 ** 9))
     warm = int(config.get("warmup_steps", 0))
-    step0 = step       # resume offset, bound once: the trainer passes its own optimizer-step count (1, 2, ...) as `s`
+    step0 = step       # resume offset, bound once: the trainer passes the number of COMPLETED optimizer steps (0, 1, ...) as `s` (LambdaLR's convention)
     trainer = engine.DataParallelTrainer(
         model, lr=config["lr"], optimizer="AdamW", weight_decay=config["weight_decay"],
         grad_accum_steps=config["gradient_accumulation_steps"],

@@ -16,6 +16,19 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffast-math", "
          "-Wno-unused-value"]
 
 
+def source_stamp():
+    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: names the code a profile was taken from on
+    a box that has no git history (profiles/traffic_rNN.json carries it, bench.py compares it with the running tree)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "kalle_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _needs(obj, deps):
     if not os.path.exists(obj):
         return True

@@ -11,6 +11,7 @@
 //   activation       dx, dalpha, dbeta : act_bwd_kernel (SnakeBeta / ELU), per-channel reductions added atomically;
 //   bias / tanh                : chan_sum_kernel, tanh_bwd_kernel;
 //   weight norm      dg, dv    : wn_bwd_kernel (w = g v / ||v||, one workgroup per slice of dim 0).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ dalpha, float* __restrict__ dbeta, int C, int L,
                                                       int seg) {
     __shared__ float red[16];
-    const int row = blockIdx.y, c = row % C;
-    const int l0 = blockIdx.x * seg, l1 = min(l0 + seg, L);
+    const int row = blockIdx.x, c = row % C;          // (rows on grid x: B * C exceeds grid y's 65535 at 2048 channels x B >= 32)
+    const int l0 = blockIdx.y * seg, l1 = min(l0 + seg, L);
     const float* xr = x + (int64_t)row * L;
     const float* gr = g + (int64_t)row * L;
     float* dr = dx + (int64_t)row * L;
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const float* 
 __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int L,
                                                        int seg) {
     __shared__ float red[16];
-    const int row = blockIdx.y, c = row % C;
-    const int l0 = blockIdx.x * seg, l1 = min(l0 + seg, L);
+    const int row = blockIdx.x, c = row % C;          // (rows on grid x: B * C exceeds grid y's 65535 at 2048 channels x B >= 32)
+    const int l0 = blockIdx.y * seg, l1 = min(l0 + seg, L);
     const float* xr = x + (int64_t)row * L;
     float s = 0.f;
     for (int l = l0 + threadIdx.x; l < l1; l += 256) s += xr[l];
@@ -265,11 +266,11 @@ extern "C" int kalle_conv_wgrad(const float* U, const float* V, float* dW, int B
 
 extern "C" int kalle_act_bwd(const float* x, const float* g, float* dx, const kalle_act* act, float* dalpha, float* dbeta, int B,
                              int C, int L, void* stream) {
-    if (!x || !g || !dx || !act || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 65535) return KALLE_ERR_ARG;
+    if (!x || !g || !dx || !act || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 0x7fffffff) return KALLE_ERR_ARG;
     if (act->code < 0 || act->code > 2 || (act->code == 1 && (!act->alpha || !act->beta))) return KALLE_ERR_ARG;
     if (act->code == 1 && ((dalpha == nullptr) != (dbeta == nullptr))) return KALLE_ERR_ARG;
-    const int seg = 8192;
-    KALLE_LAUNCH(act_bwd_kernel, dim3((L + seg - 1) / seg, B * C), dim3(256), 0, static_cast<hipStream_t>(stream), x, g, dx,
+    const int seg = std::max(8192, (L + 65534) / 65535);
+    KALLE_LAUNCH(act_bwd_kernel, dim3(B * C, (L + seg - 1) / seg), dim3(256), 0, static_cast<hipStream_t>(stream), x, g, dx,
                  act->code, act->alpha, act->beta, act->logscale, dalpha, dbeta, C, L, seg);
     return kalle_check_launch();
 }
@@ -295,9 +296,9 @@ extern "C" int kalle_upsample_nearest(const float* x, float* y, int64_t rows, in
 }
 
 extern "C" int kalle_channel_sum(const float* x, float* out, int B, int C, int L, void* stream) {
-    if (!x || !out || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 65535) return KALLE_ERR_ARG;
-    const int seg = 16384;
-    KALLE_LAUNCH(chan_sum_kernel, dim3((L + seg - 1) / seg, B * C), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, C, L,
+    if (!x || !out || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 0x7fffffff) return KALLE_ERR_ARG;
+    const int seg = std::max(16384, (L + 65534) / 65535);
+    KALLE_LAUNCH(chan_sum_kernel, dim3(B * C, (L + seg - 1) / seg), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, C, L,
                  seg);
     return kalle_check_launch();
 }

@@ -67,9 +67,27 @@ class GradOut:
         self.grads = {}
         self.deferred = None            # list of (name, dy, x) while a block's weight gradients are being collected
         self.wgrad_overwrite = False    # trainer, first micro-batch: weight-gradient sinks are NOT pre-cleared - write, don't add
+        self.touched = set()            # sink names some kernel of this backward pass has written (or added into)
 
     def _sink(self, name):
-        return self.sinks.get(self.prefix + name)
+        s = self.sinks.get(self.prefix + name)
+        if s is not None:
+            self.touched.add(self.prefix + name)
+        return s
+
+    def zero_unwritten(self):
+        """Sinks that NO kernel of this backward pass wrote - the cross-attention of a block called with context=None
+        (transformer.py:684-693 skips it), a sub-module that only runs in a later micro-batch - must read as zero when the
+        pass is the one that (re)defines the buffers: in overwrite mode the matrices are not pre-cleared (engine.backward
+        clears only the vectors at the head of the bucket), without accumulation nothing is.  Otherwise last step's values
+        would reach the all-reduce and Adam."""
+        if not self.sinks:
+            return
+        for full, s in self.sinks.items():
+            if full in self.touched:
+                continue
+            if not self.accumulate or (self.wgrad_overwrite and s.dim() >= 2):
+                s.zero_()
 
     def defer(self):
         """collect the weight gradients of a block and launch them together in flush() (kalle_gemm_wgrad_group)"""
@@ -496,4 +514,5 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         dsg = dgrad(dmb, p.wmod, out_dtype=F32)
         dglobal = ops.silu_bwd(dsg, sv.x_global)
     go.flush()
+    go.zero_unwritten()
     return dx, dctx, dglobal, go, dxb

@@ -213,9 +213,9 @@ class DataParallelTrainer:
         # its all-reduce has landed), so its slice of the fused Adam runs right then on a side stream - an HBM-bound pass under
         # the MFMA-bound GEMMs of the blocks still to come - instead of one 5.4 ms pass over all 1.05 B parameters at the end.
         # (KALLE_OVERLAP_ADAM=0: the single pass at the end of the step.)
-        self.overlap_adam = (device.type == "cuda" and os.environ.get("KALLE_OVERLAP_ADAM", "1") != "0"
-                             and comm_dtype == torch.float32)
+        self.overlap_adam = device.type == "cuda" and os.environ.get("KALLE_OVERLAP_ADAM", "1") != "0"
         self._opt_stream = torch.cuda.Stream(device=device) if self.overlap_adam else None
+        self._comm_stream = torch.cuda.Stream(device=device) if self.overlap_adam else None
         self._opt_done = set()            # bucket keys whose Adam slice of the current optimizer step has been queued
         self._opt_lr = None               # learning rate of the optimizer step in progress (set when its backward starts)
         self._overlap_now = False         # decided per optimizer step: only where the backward GEMMs are long enough to hide it
@@ -232,20 +232,51 @@ class DataParallelTrainer:
                 p._kalle_grad_sink = self.flat.grad_view(n)
 
     # -- gradient communication ---------------------------------------------------------------------------
+    def _comm_active(self):
+        return self.world > 1 or (dist.is_initialized() and bool(os.environ.get("KALLE_FORCE_COMM")))
+
     def _allreduce(self, buf, defer=True):
-        """starts the all-reduce of one bucket; returns the work handle (None without communication).  defer: the wait is left
-        to _finish_comm (end of the backward pass); otherwise the caller waits where it needs the result"""
-        if self.world == 1 and not (dist.is_initialized() and os.environ.get("KALLE_FORCE_COMM")):
-            return None
+        """starts the all-reduce of one bucket; returns (work handle | None, low-precision staging tensor | None).  defer: the
+        wait (and the copy back from a low-precision bucket) is left to _finish_comm at the end of the backward pass;
+        otherwise the caller waits where it needs the result"""
+        if not self._comm_active():
+            return None, None
         if self.comm_dtype == torch.float32 or not buf.is_cuda:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             if defer:
                 self._pending.append((work, None, None))
-            return work
+            return work, None
         low = ops.cast(buf, self.comm_dtype)
         work = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append((work, low, buf))
-        return work
+        if defer:
+            self._pending.append((work, low, buf))
+        return work, low
+
+    def _queue_bucket(self, keys, ev):
+        """Overlapped path, three streams.  COMM stream: waits for the compute stream's event (the bucket's gradient kernels),
+        casts if the buckets travel in low precision and issues the all-reduce - RCCL's own stream orders itself behind the
+        stream the collective is issued from, so bucket k+1's all-reduce depends on the backward pass only, never on the
+        optimizer.  OPTIMIZER stream: waits for the all-reduce's completion (work.wait() blocks that stream, not the host),
+        copies a low-precision result back into the fp32 bucket and runs the bucket's slice of the fused Adam - under the
+        backward kernels of the blocks still to come and under the next buckets' all-reduces."""
+        works = []
+        if self._comm_active():
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                for key in keys:
+                    buf = self.flat.bucket_grad(key)
+                    work, low = self._allreduce(buf, defer=False)
+                    works.append((work, low, buf))
+        with torch.cuda.stream(self._opt_stream):
+            self._opt_stream.wait_event(ev)
+            for work, low, buf in works:
+                work.wait()
+                if low is not None:
+                    low.record_stream(self._opt_stream)          # (allocated on the comm stream, read here)
+                    ops.copy_rows(low, buf, 1, 1, buf.numel(), 0, buf.numel(), 0, buf.numel())
+                self._comm_events += 1
+            for key in keys:
+                self._adam_bucket(key)
 
     def _on_block_done(self, blk):
         """called (from autograd's backward) right after a block's backward kernels were queued"""
@@ -255,17 +286,9 @@ class DataParallelTrainer:
         if not self._overlap_now:
             self._allreduce(self.flat.bucket_grad(key))
             return
-        # the bucket's all-reduce, then its Adam slice, on the optimizer stream behind an event of the compute stream
-        cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
-        ev.record(cur)
-        with torch.cuda.stream(self._opt_stream):
-            self._opt_stream.wait_event(ev)
-            work = self._allreduce(self.flat.bucket_grad(key), defer=False)
-            if work is not None:
-                work.wait()                     # (blocks the optimizer stream, not the host and not the compute stream)
-                self._comm_events += 1
-            self._adam_bucket(key)
+        ev.record(torch.cuda.current_stream())
+        self._queue_bucket([key], ev)
 
     def _begin_optimizer_step(self):
         """fixes the step number and learning rate of the optimizer step whose last micro-batch is about to run backward"""
@@ -295,26 +318,14 @@ class DataParallelTrainer:
         return (self.micro + 1) % self.grad_accum_steps == 0
 
     def _finish_comm(self):
-        if self._boundary():
-            for key in ("_rest", "_vae"):
-                if key in self.flat.bucket_range:
-                    self._allreduce(self.flat.bucket_grad(key))
         if self._overlap_now and self._boundary():
-            # what the bucket hooks did not cover (embedders, in / out projections, a trained VAE): communicated above, waited
-            # for and updated on the optimizer stream too; the compute stream then waits for that stream ONCE - the time it
-            # sits there is what neither the all-reduces nor the optimizer slices managed to hide behind the backward pass
+            # what the bucket hooks did not cover (embedders, in / out projections, a trained VAE) goes the same way; the compute
+            # stream then waits for the optimizer stream ONCE - the time it sits there is what neither the all-reduces nor the
+            # optimizer slices managed to hide behind the backward pass
             cur = torch.cuda.current_stream()
             ev = torch.cuda.Event()
             ev.record(cur)
-            with torch.cuda.stream(self._opt_stream):
-                self._opt_stream.wait_event(ev)
-                for work, low, dst in self._pending:
-                    work.wait()
-                self._comm_events += len(self._pending)
-                self._pending = []
-                for key in self.flat.bucket_keys:
-                    if key not in self._opt_done:
-                        self._adam_bucket(key)
+            self._queue_bucket([k for k in self.flat.bucket_keys if k not in self._opt_done], ev)
             timed = self.comm_timing is not None
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -324,6 +335,10 @@ class DataParallelTrainer:
                 e1.record()
                 self.comm_timing.append((e0, e1, self._comm_events))
             return
+        if self._boundary():
+            for key in ("_rest", "_vae"):
+                if key in self.flat.bucket_range:
+                    self._allreduce(self.flat.bucket_grad(key))
         timed = self.comm_timing is not None and self._pending and self.flat.grad.is_cuda
         if timed:
             # exposed (not overlapped) all-reduce time = how long the compute stream sits in the waits below: nothing is
@@ -441,7 +456,12 @@ class DataParallelTrainer:
     #    accumulation phase and the EMA too, so that a resumed run continues bit for bit) -------------------------------------
     def state_dict(self):
         sd = {"model": self.model.state_dict(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-              "step": self.step_count, "micro": self.micro}
+              "step": self.step_count, "micro": self.micro,
+              # the moments are raw flat tensors: their meaning is the flat layout (name -> (offset, numel)), which travels with
+              # them and is checked on load (a checkpoint written under another layout has the same total size)
+              "layout": {n: list(v) for n, v in self.flat.slices.items()}}
+        if self.micro % self.grad_accum_steps != 0:
+            sd["grad"] = self.flat.grad        # a half-finished accumulation window: the micro-batches already summed
         if getattr(self, "ema", None) is not None:
             sc = self.ema_schedule
             sd["ema"] = self.ema
@@ -451,11 +471,25 @@ class DataParallelTrainer:
         return sd
 
     def load_state_dict(self, sd):
+        layout = sd.get("layout")
+        if layout is not None:
+            mine = {n: list(v) for n, v in self.flat.slices.items()}
+            if layout != mine:
+                diff = [n for n in mine if layout.get(n) != mine[n]][:4]
+                raise ValueError(f"checkpoint was written under another flat parameter layout (first differences: {diff}); "
+                                 "the Adam moments cannot be mapped")
+        elif sd["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError("checkpoint moments do not match this trainer's flat buffers")
         self.model.load_state_dict(sd["model"], strict=False)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = sd["step"]
         self.micro = sd.get("micro", 0)
+        if self.micro % self.grad_accum_steps != 0:
+            if "grad" in sd:
+                self.flat.grad.copy_(sd["grad"])
+            else:       # (older checkpoints: the partial sums are gone - restart the window rather than scale an empty buffer)
+                self.micro -= self.micro % self.grad_accum_steps
         if "ema" in sd:
             es = dict(sd["ema_schedule"])
             step, initted = es.pop("step"), es.pop("initted")

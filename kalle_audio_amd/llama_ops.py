@@ -108,6 +108,7 @@ def layer_bwd(p, saved, g, B, L, rope, mask8, go=None, g_bf16=None, want_dx_bf16
     dxb = torch.empty((M, D), device=g.device, dtype=BF16) if want_dx_bf16 else None
     dx = go.rms("input_layernorm.weight", dh1, x, p.g1, rr1, dres=dx2, dx_bf16=dxb)
     go.flush()
+    go.zero_unwritten()
     return dx, dxb, go
 
 

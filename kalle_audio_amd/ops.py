@@ -364,8 +364,14 @@ def grad_cast(g, nbatch, rows_per_batch, gate=None, x_out=None, x_in=None, row_m
     return gb, dgate
 
 
+WEIGHTS_EPOCH = 0      # bumped by every launch that writes weights through a raw pointer (torch's `_version` does not see it):
+                       # part of the key of every cache derived from weights (stacked k | v weights, captured graphs)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, param_bf16, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               decoupled=False, step=1, grad_scale=1.0):
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
     lib = _lib.load()
     check(lib.kalle_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param_bf16), param.numel(), lr,
                               beta1, beta2, eps, weight_decay, int(decoupled), step, grad_scale, _stream()),

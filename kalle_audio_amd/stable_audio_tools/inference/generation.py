@@ -45,14 +45,19 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
     # One sampler step is ~400 launches that take less GPU time than the host needs to issue them: the denoiser call is captured
     # into a HIP graph once per shape signature and replayed (kalle_audio_amd/graph.py; bit-identical to the eager launches;
     # KALLE_SAMPLE_GRAPH=0 keeps the eager path).  Only frozen models: a captured graph does not see parameter updates' new
-    # bf16 copies.
+    # bf16 copies.  "Frozen" is requires_grad=False, not immutable - load_state_dict of the next checkpoint or an EMA swap
+    # changes the weights in place, and a re-cast bf16 copy lives at a new address: the captured graphs are dropped whenever the
+    # weights' fingerprint (every parameter's version and address + the raw-pointer write epoch) has moved.
     denoiser = model.model
     frozen = not any(p.requires_grad for p in denoiser.parameters())
     if steps >= 4 and frozen and os.environ.get("KALLE_SAMPLE_GRAPH", "1") != "0":     # (the samplers run under no_grad)
+        from ... import ops
         from ...graph import GraphedForward
+        fp = (tuple((p._version, p.data_ptr()) for p in denoiser.parameters()), ops.WEIGHTS_EPOCH)
         g = getattr(model, "_kalle_graphed", None)
-        if g is None or g.fn is not denoiser:
+        if g is None or g.fn is not denoiser or getattr(g, "weights_fingerprint", None) != fp:
             g = GraphedForward(denoiser)
+            g.weights_fingerprint = fp
             object.__setattr__(model, "_kalle_graphed", g)      # (not a submodule: keeps it out of state_dict / parameters)
         denoiser = g
     if model.diffusion_objective == "v":

@@ -400,9 +400,20 @@ class AudioAutoencoder(nn.Module):
         x = x.contiguous()
         y_final = None
         per_pass = max(1, self.chunk_batch // B)
+        differentiable = _wants_grad(self, x)     # enable_grad pretransform (models/factory.py:77-80) with chunked=True
         for g0 in range(0, len(plan), per_pass):
             grp = plan[g0:g0 + per_pass]
             n = len(grp)
+            if differentiable:
+                # the raw segment-copy kernels leave no autograd nodes: gather and paste with torch slicing, which - like the
+                # reference's slice-assign loop (autoencoders.py:468-494, 530-558) - is differentiable; same plan, same samples
+                y = fn(torch.cat([x[:, :, p[0]:p[0] + chunk_in] for p in grp], dim=0))
+                if y_final is None:
+                    y_final = torch.zeros((B, y.shape[1], total_out), device=x.device, dtype=y.dtype)
+                for i, (_, keep, dst, ln) in enumerate(grp):
+                    if ln > 0:
+                        y_final[:, :, dst:dst + ln] = y[i * B:(i + 1) * B, :, keep:keep + ln]
+                continue
             stacked = torch.empty((n * B, C, chunk_in), device=x.device, dtype=x.dtype)
             ops.segment_copy(x, stacked, [p[0] for p in grp], [0] * n, [chunk_in] * n, B, C,
                              src_strides=(0, x.stride(0), x.stride(1)), dst_strides=(B * C * chunk_in, C * chunk_in, chunk_in))

@@ -234,7 +234,9 @@ class ContinuousTransformer(nn.Module):
         w_all = None
         frozen = not torch.is_grad_enabled() and all(getattr(w, "_kalle_bf16_pinned", None) is None for w in ws)
         if frozen:      # inference: the stacked weights are rebuilt only when a parameter changed (sampler loops call this per step)
-            key = tuple(w._version for w in ws) + (ws[0].device,)
+            # (`_version` misses writes through the raw pointer - engine.FusedAdam - hence the epoch; `data_ptr` a re-pointed
+            # parameter)
+            key = tuple((w._version, w.data_ptr()) for w in ws) + (ws[0].device, KF.ops.WEIGHTS_EPOCH)
             hit = getattr(self, "_kalle_wall", None)
             if hit is not None and hit[0] == key:
                 w_all = hit[1]

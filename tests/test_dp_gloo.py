@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the data-parallel machinery of engine.py (flat buckets, per-block bucket all-reduce
+"""CPU, world_size 2 / 4 / 8 over gloo: the data-parallel machinery of engine.py (flat buckets, per-block bucket all-reduce
 issued from the backward hook, gradient-accumulation boundaries, rank-0 weight broadcast, rank-offset data seeds).
 The kernels themselves need the GPU; here the block backward is simulated by writing known values into the same
 gradient sinks the wgrad GEMMs write into, so the communication path is exercised exactly as in training."""
@@ -23,10 +23,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, accum, q):
+def _worker(rank, world, port, accum, steps, q):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port))
+        torch.set_num_threads(1)                 # (up to 8 ranks share this container's 8 cores)
         from kalle_audio_amd import engine
         from kalle_audio_amd.stable_audio_tools.models.dit import DiffusionTransformer
         r, w, _ = engine.init_distributed(backend="gloo")
@@ -44,38 +45,42 @@ def _worker(rank, world, port, accum, q):
         assert p0.data_ptr() == tr.flat.param[tr.flat.slices[name0][0]:].data_ptr()
         assert p0.grad.data_ptr() == tr.flat.grad_view(name0).data_ptr()
         assert sorted(tr.flat.bucket_keys) == ["_rest", "transformer.layers.0.", "transformer.layers.1."]
-        # (2) simulate `accum` micro-batches: every sink gets (rank+1)*(micro+1) added, "_rest" likewise
-        for micro in range(accum):
-            first = micro == 0
-            val = float((rank + 1) * (micro + 1))
-            if first:
-                tr.flat.bucket_grad("_rest").zero_()
-            tr.flat.bucket_grad("_rest").add_(val)
-            for _, blk in reversed(tr.blocks):
-                for sink in blk._kalle_grad_sinks.values():
-                    if first:
-                        sink.fill_(val)            # accumulate=False: the GEMM overwrites
-                    else:
-                        sink.add_(val)             # accumulate=True
-                tr._on_block_done(blk)             # what TransformerBlockFn.backward calls
-            issued = len(tr._pending)
-            assert issued == (len(tr.blocks) if tr._boundary() else 0)
-            tr._finish_comm()
-            tr.micro += 1
-        # (3) after the boundary every gradient element = sum over ranks of sum over micro-batches
-        expect = sum((rk + 1) * (m + 1) for rk in range(world) for m in range(accum))
-        for name in tr.flat.names:
-            g = tr.flat.grad_view(name)
-            assert torch.all(g == expect), (name, g.flatten()[:3], expect)
+        # (2) simulate `steps` optimizer steps of `accum` micro-batches each: every sink gets (rank+1)*(micro+1)*(step+1) added,
+        #     "_rest" likewise; the all-reduce must fire on the LAST micro-batch of every window and on no other
+        for ostep in range(steps):
+            for micro in range(accum):
+                first = micro == 0
+                val = float((rank + 1) * (micro + 1) * (ostep + 1))
+                if first:
+                    tr.flat.bucket_grad("_rest").zero_()
+                tr.flat.bucket_grad("_rest").add_(val)
+                for _, blk in reversed(tr.blocks):
+                    for sink in blk._kalle_grad_sinks.values():
+                        if first:
+                            sink.fill_(val)            # accumulate=False: the GEMM overwrites
+                        else:
+                            sink.add_(val)             # accumulate=True
+                    tr._on_block_done(blk)             # what TransformerBlockFn.backward calls
+                issued = len(tr._pending)
+                assert issued == (len(tr.blocks) if tr._boundary() else 0), (ostep, micro, issued)
+                assert tr._boundary() == (micro == accum - 1)
+                tr._finish_comm()
+                assert tr._pending == []
+                tr.micro += 1
+            # (3) after the boundary every gradient element = sum over ranks of sum over the window's micro-batches
+            expect = sum((rk + 1) * (m + 1) * (ostep + 1) for rk in range(world) for m in range(accum))
+            for name in tr.flat.names:
+                g = tr.flat.grad_view(name)
+                assert torch.all(g == expect), (name, g.flatten()[:3], expect)
         # the optimizer divides by world*accum (engine.optimizer_step grad_scale) -> mean gradient
-        assert abs(expect / (world * accum) - sum((rk + 1) for rk in range(world)) / world *
+        assert abs(expect / (world * accum) - steps * sum((rk + 1) for rk in range(world)) / world *
                    sum(m + 1 for m in range(accum)) / accum) < 1e-9
         # (4) per-rank data shards differ (bench.py seeds 1234 + rank)
         g = torch.Generator().manual_seed(1234 + rank)
         x = torch.randn(4, generator=g)
         xs = [torch.zeros(4) for _ in range(world)]
         dist.all_gather(xs, x)
-        assert not torch.equal(xs[0], xs[1])
+        assert all(not torch.equal(xs[i], xs[j]) for i in range(world) for j in range(i))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -84,16 +89,15 @@ def _worker(rank, world, port, accum, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("accum", [1, 2])
-def test_bucketed_allreduce_two_ranks_gloo(accum):
-    world = 2
+@pytest.mark.parametrize("world,accum,steps", [(2, 1, 1), (2, 2, 2), (4, 3, 2), (8, 2, 3)])
+def test_bucketed_allreduce_gloo(world, accum, steps):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, accum, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, accum, steps, q)) for r in range(world)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=180) for _ in ps]
+    res = [q.get(timeout=300) for _ in ps]
     for p in ps:
         p.join(timeout=60)
     for rank, msg in res:

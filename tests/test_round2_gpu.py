@@ -620,12 +620,15 @@ def test_trainer_state_dict_roundtrip_resumes(dev):
         ta.train_step(a, lat[:2] if i % 2 == 0 else lat[2:], t[:2], noise[:2], _slice_cond(cond, slice(0, 2)))
     sd = {k: (v.clone() if torch.is_tensor(v) else (dict(v) if isinstance(v, dict) else v)) for k, v in ta.state_dict().items()}
     sd["model"] = {k: v.clone() for k, v in sd["model"].items()}
-    grad_mid = ta.flat.grad.clone()
     b = _small_dit(dev, seed=99)                      # different weights: everything must come from the checkpoint
     tb = engine.DataParallelTrainer(b, lr=1e-3, optimizer="AdamW", weight_decay=0.01, grad_accum_steps=2,
                                     lr_schedule=lambda s: engine.cosine_with_warmup(s, 2, 50))
+    assert "grad" in sd and "layout" in sd            # the half-finished accumulation window travels with the checkpoint
     tb.load_state_dict(sd)
-    tb.flat.grad.copy_(grad_mid)                      # (the half-finished accumulation window travels with the gradient buffer)
+    assert torch.equal(tb.flat.grad, sd["grad"])
+    bad = dict(sd, layout={k: [v[0] + 64, v[1]] for k, v in sd["layout"].items()})
+    with pytest.raises(ValueError):                   # moments written under another flat layout must not load silently
+        tb.load_state_dict(bad)
     assert tb.step_count == ta.step_count == 2 and tb.micro == ta.micro == 5
     assert torch.equal(tb.flat.param, ta.flat.param) and torch.equal(tb.flat.param_bf16, ta.flat.param_bf16)
     assert torch.equal(tb.ema, ta.ema)

@@ -1,0 +1,266 @@
+"""-m gpu, round 3: the HEADLINE configuration (24 blocks, D = 1536, 24 heads, 1024 latent channels, 125 + 1 tokens, 130 x 768
+conditioning tokens) pinned end to end against the CPU oracle, the grouped weight-gradient launch at the benchmark's own plan
+(32256 tokens x the seven matrices of a block), the sweep widths of SURVEY 8(d) through a `-m gpu` check, and the trainer /
+cache hazards the round-2 review found (stale gradients of sub-modules that did not run, stale weight caches).
+
+Tolerances: loss |d| <= 1e-2 relative, cosine >= 0.999 for the 24-block output, gradients rel-L2 <= 3e-2 through
+24 bf16 layers (2e-2 for a single block)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import kalle_oracle as ko  # noqa: E402
+from test_modules_gpu import cosine, rel  # noqa: E402
+from test_round2_gpu import _batch, _slice_cond, _small_dit  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _drop_in_installed():
+    import kalle_audio_amd
+    kalle_audio_amd.install()
+
+
+# ------------------------------------------------------------------------------------------------ headline configuration
+def test_headline_config_train_step_vs_oracle(dev):
+    """bench.build_model (the benchmark's exact model) runs ONE train step on 2 clips through the trainer; the CPU oracle runs
+    the same step in fp32 on the same weights and inputs (as bench.cpu_baseline does).  Compared: the loss, the 24-block
+    output, and FULL gradient tensors from the first, a middle and the last block plus the input projection - the drift of
+    bf16 operands through 24 residual layers (transformer.py:758-812, dit.py:135-229), never measured before round 3."""
+    import bench
+    from kalle_audio_amd import engine
+    from kalle_audio_amd.stable_audio_tools.training.diffusion import diffusion_train_step
+    cfg = dict(bench.CFG, io_channels=1024, global_cond_type="prepend")
+    model = bench.build_model(dev, cfg=cfg)
+    lat, noise, t, cond = bench.make_batch(2, dev, 99, cfg)
+    sd = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in model.model.model.named_parameters()}
+    with torch.no_grad():
+        _, info = diffusion_train_step(model, lat, t, noise, cond, objective="v")
+    out_gpu = info["output"].float().cpu()
+    tr = engine.DataParallelTrainer(model, lr=0.0, optimizer="Adam")
+    loss = tr.train_step(model, lat, t, noise, cond, objective="v")
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ocfg = dict(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], global_cond_type="prepend")
+    loss_ref, out_ref, _, _ = ko.train_step_loss(sd, ocfg, lat.cpu(), noise.cpu(), t.cpu(), "v",
+                                                 cross_attn_cond=cond["prompt"][0].cpu(), global_embed=cond["global"][0].cpu())
+    loss_ref.backward()
+    lv, lr_ = loss.item(), loss_ref.item()
+    margins = {"loss_rel": abs(lv - lr_) / abs(lr_), "out_cos": cosine(out_gpu, out_ref.detach()),
+               "out_rel": rel(out_gpu, out_ref.detach())}
+    names = ["transformer.project_in.weight", "transformer.project_out.weight"]
+    for layer in (0, 11, 23):
+        names += [f"transformer.layers.{layer}.{n}" for n in ("self_attn.to_qkv.weight", "ff.ff.0.proj.weight",
+                                                              "cross_attn.to_kv.weight", "ff.ff.2.weight")]
+    names += ["transformer.layers.23.pre_norm.gamma", "transformer.layers.0.ff.ff.0.proj.bias", "to_timestep_embed.0.weight"]
+    for n in names:
+        margins[n] = rel(tr.flat.grad_view("model.model." + n).float().cpu(), sd[n].grad)
+    print("HEADLINE_MARGINS " + " ".join(f"{k}={v:.3e}" for k, v in margins.items()))
+    assert margins["loss_rel"] <= 1e-2, margins
+    assert margins["out_cos"] >= 0.999, margins
+    for n in names:
+        assert margins[n] <= 3e-2, (n, margins[n])
+
+
+SEVEN = [(4608, 1536), (1536, 1536), (1536, 1536), (1536, 768), (1536, 1536), (12288, 1536), (1536, 6144)]
+
+
+@pytest.mark.parametrize("overwrite", [True, False])
+def test_grouped_wgrad_kernel_at_the_bench_plan(dev, overwrite):
+    """kalle_gemm_wgrad_group at the shapes the headline number runs on: 32256 tokens (33280 context tokens for to_kv, whose dY
+    is a column slice of the stacked k | v gradient of all layers), the seven matrices of a block - the "512 whole tiles +
+    154 x 3 slices" plan of DESIGN 5.2 - overwriting and accumulating, against an fp64 product of the same bf16 operands"""
+    from kalle_audio_amd import ops
+    tokens, ctx_tokens = 256 * 126, 256 * 130
+    g = torch.Generator(device=dev).manual_seed(5 + overwrite)
+    probs, refs = [], []
+    for i, (n, k) in enumerate(SEVEN):
+        rows = ctx_tokens if k == 768 else tokens
+        if k == 768:        # strided dY: columns [n, 2n) of a [rows, 3n] buffer (dit_ops.ContextKV)
+            big = (torch.randn(rows, 3 * n, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+            dy = big[:, n:2 * n]
+        else:
+            dy = (torch.randn(rows, n, generator=g, device=dev) * 0.5).to(torch.bfloat16)
+        x = torch.randn(rows, k, generator=g, device=dev).to(torch.bfloat16)
+        base = torch.randn(n, k, generator=g, device=dev)
+        ref = dy.double().T @ x.double()
+        refs.append((ref if overwrite else ref + base.double()).float())
+        del ref
+        probs.append((dy, x, base.clone()))
+    assert ops.gemm_wgrad_group(probs, overwrite=overwrite)
+    torch.cuda.synchronize()
+    for (dy, x, out), ref in zip(probs, refs):
+        assert rel(out, ref) < 2e-5, (tuple(out.shape), rel(out, ref))
+
+
+@pytest.mark.parametrize("io_channels,frames", [(64, 125), (512, 125), (1024, 375)])
+def test_full_width_sweep_axes_step_properties(dev, io_channels, frames):
+    """the other points of SURVEY 8(d)'s sweep at full width and depth (io_channels 64 / 512; 375 frames = three key blocks in
+    the self-attention): a train step is reproducible, the gradient of a batch is the mean of its halves' gradients, and one
+    oracle-checked quantity per point - the loss of the step against the CPU oracle on the same weights"""
+    import bench
+    from kalle_audio_amd import engine
+    cfg = dict(bench.CFG, io_channels=io_channels, global_cond_type="prepend")
+    model = bench.build_model(dev, cfg=cfg)
+    lat, noise, t, cond = bench.make_batch(4, dev, 31, cfg, T=frames)
+    sd = {n: p.detach().float().cpu().clone() for n, p in model.model.model.named_parameters()}
+    tr = engine.DataParallelTrainer(model, lr=0.0, optimizer="Adam")
+
+    def grads(sl, parts=1):
+        tr.grad_accum_steps, tr.micro = parts, 0
+        n = (sl.stop - sl.start) // parts
+        losses = []
+        for i in range(parts):
+            s = slice(sl.start + i * n, sl.start + (i + 1) * n)
+            losses.append(tr.train_step(model, lat[s], t[s], noise[s], _slice_cond(cond, s), objective="v"))
+        torch.cuda.synchronize()
+        return torch.stack(losses).mean().item(), tr.flat.grad.clone()
+
+    l1, g1 = grads(slice(0, 4))
+    l2, g2 = grads(slice(0, 4))
+    assert abs(l1 - l2) < 1e-5 * abs(l1) and rel(g2, g1) < 1e-4
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    la, ga = grads(slice(0, 4), parts=2)
+    assert abs(la - l1) < 2e-3 * abs(l1) and rel(ga * 0.5, g1) < 2e-2, (la, l1, rel(ga * 0.5, g1))
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ocfg = dict(embed_dim=cfg["embed_dim"], depth=cfg["depth"], num_heads=cfg["num_heads"], global_cond_type="prepend")
+    with torch.no_grad():
+        s = slice(0, 1)
+        loss_ref, *_ = ko.train_step_loss(sd, ocfg, lat[s].cpu(), noise[s].cpu(), t[s].cpu(), "v",
+                                          cross_attn_cond=cond["prompt"][0][s].cpu(), global_embed=cond["global"][0][s].cpu())
+    tr.grad_accum_steps, tr.micro = 1, 0
+    got = tr.train_step(model, lat[s], t[s], noise[s], _slice_cond(cond, s), objective="v").item()
+    assert abs(got - loss_ref.item()) <= 1e-2 * abs(loss_ref.item()), (got, loss_ref.item())
+
+
+# ------------------------------------------------------------------------------------------------ stale gradients
+@pytest.mark.parametrize("rows_mode", ["grouped", "plain"])
+def test_no_stale_gradients_for_submodules_that_did_not_run(dev, monkeypatch, rows_mode):
+    """A block called with context=None skips its cross-attention (transformer.py:684-693).  In overwrite mode the trainer does
+    not pre-clear the matrix gradients, so the cross-attention sinks would keep LAST step's values and Adam would apply them:
+    step with context, then step without - the cross-attention gradients must be exactly zero and Adam's second step must
+    move those weights by momentum only (never by a stale gradient)."""
+    from kalle_audio_amd import dit_ops, engine
+    if rows_mode == "plain":
+        monkeypatch.setattr(dit_ops, "GROUP_WGRAD", False)
+    m = _small_dit(dev)
+    tr = engine.DataParallelTrainer(m, lr=1e-3, optimizer="Adam")
+    lat, noise, t, cond = _batch(dev, 4, 11)        # 4 x 126 = 504 rows: a multiple of 8, so the grouped launch is eligible
+    tr.train_step(m, lat, t, noise, cond)
+    torch.cuda.synchronize()
+    assert all(blk._kalle_wgrad_overwrite == (rows_mode == "grouped") for _, blk in tr.blocks)
+    cross = [n for n in tr.flat.names if ".cross_attn." in n or ".cross_attend_norm." in n]
+    assert cross and all(tr.flat.grad_view(n).abs().max() > 0 for n in cross if "weight" in n)
+    w1 = {n: tr.flat.params[n].detach().clone() for n in cross}
+    no_ctx = {"g": cond["g"]}
+    m.cross_attn_cond_ids = []                      # the wrapper now hands the DiT no cross-attention conditioning
+    tr.train_step(m, lat, t, noise, no_ctx)
+    torch.cuda.synchronize()
+    for n in cross:
+        assert tr.flat.grad_view(n).abs().max().item() == 0.0, n
+    # Adam with a zero gradient: update = -lr * (b1 m1) / (1 - b1^2) / (sqrt(b2 v1 / (1 - b2^2)) + eps) - bounded by lr, and in
+    # the direction of the FIRST step's gradient; a stale gradient would have produced a full second step (|d| ~ lr again with
+    # m = (1 - b1^2)-corrected mean of two equal gradients: ratio ~1.0, against ~0.53 = b1 (1-b1) / (1 - b1^2) / sqrt(b2 ...) here)
+    for n in cross:
+        if "weight" not in n or tr.flat.params[n].dim() < 2:
+            continue
+        d1 = (w1[n] - 0).float()                    # weights after step 1
+        d2 = tr.flat.params[n].detach().float() - d1
+        s, cnt = tr.flat.slices[n]
+        first = tr.exp_avg[s:s + cnt].view(d2.shape)            # m2 = b1 * m1 (zero gradient)
+        big = first.abs() > 1e-3 * first.abs().max()
+        ratio = (d2[big].abs() / 1e-3).median().item()
+        assert 0.3 < ratio < 0.8, (n, ratio)       # momentum-only step; a stale gradient gives ~1.0
+
+
+# ------------------------------------------------------------------------------------------------ stale weight caches (advisor)
+def test_stacked_context_weights_follow_fused_adam(dev, monkeypatch):
+    """FusedAdam writes parameters through the raw pointer (p._version does not move): FusedAdam step -> no_grad forward ->
+    step -> no_grad forward must project the context with the CURRENT to_kv weights (the no-grad cache of the stacked k | v
+    weights is keyed on a write epoch too), compared against one projection per layer (KALLE_BATCH_CTX_KV=0)"""
+    from kalle_audio_amd.engine import FusedAdam
+    from stable_audio_tools.training.diffusion import diffusion_train_step
+    m = _small_dit(dev)
+    opt = FusedAdam(m.parameters(), lr=5e-3, adam_w_mode=False)
+    lat, noise, t, cond = _batch(dev, 2, 12)
+
+    def eval_out():
+        with torch.no_grad():
+            return diffusion_train_step(m, lat, t, noise, cond)[1]["output"].float().clone()
+
+    outs = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = diffusion_train_step(m, lat, t, noise, cond)
+        loss.backward()
+        opt.step()
+        outs.append(eval_out())
+    monkeypatch.setenv("KALLE_BATCH_CTX_KV", "0")
+    want = eval_out()
+    assert rel(outs[0], outs[1]) > 1e-3                   # the weights really moved between the two evaluations
+    assert rel(outs[1], want) < 1e-6, rel(outs[1], want)  # and the cached stack followed them
+
+
+def test_captured_sampler_graph_follows_new_weights(dev, monkeypatch):
+    """generate -> load_state_dict(other weights) -> generate on a frozen model: the HIP graph captured for the first weights
+    must not be replayed for the second (its kernels read the old bf16 copies); compared against KALLE_SAMPLE_GRAPH=0"""
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    a, b = _small_dit(dev, seed=70), _small_dit(dev, seed=71)
+    a.eval().requires_grad_(False)
+    _, _, _, cond = _batch(dev, 1, 13)
+    kw = dict(steps=6, cfg_scale=3.0, conditioning_tensors=cond, batch_size=1, sample_size=125, seed=7, device="cpu")
+    first = generate_diffusion_cond(a, **kw).clone()
+    assert getattr(a, "_kalle_graphed", None) is not None
+    a.load_state_dict(b.state_dict())
+    second = generate_diffusion_cond(a, **kw).clone()
+    monkeypatch.setenv("KALLE_SAMPLE_GRAPH", "0")
+    want = generate_diffusion_cond(a, **kw)
+    assert rel(first, second) > 1e-2
+    assert torch.equal(second, want)
+
+
+# ------------------------------------------------------------------------------------------------ conv backward limits (advisor)
+def test_act_bwd_and_channel_sum_beyond_65535_rows(dev):
+    """B * C > 65535 (2048 channels at per-GPU batch >= 32 during VAE fine-tuning): rows ride on grid x now"""
+    from kalle_audio_amd import conv_train
+    from stable_audio_tools.models.blocks import SnakeBeta
+    B, C, L = 40, 2048, 24
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(B, C, L, generator=g, device=dev, requires_grad=True)
+    act = SnakeBeta(C).to(dev)
+    with torch.no_grad():
+        act.alpha.normal_(0, 0.3, generator=g)
+        act.beta.normal_(0, 0.3, generator=g)
+    gy = torch.randn(B, C, L, generator=g, device=dev)
+    a, bb = act.alpha.exp()[None, :, None], act.beta.exp()[None, :, None]
+    y_ref = x + torch.sin(x * a) ** 2 / (bb + 1e-9)
+    dx_ref, da_ref, db_ref = torch.autograd.grad(y_ref, [x, act.alpha, act.beta], gy)
+    dx, da, db = conv_train.act_bwd(x.detach(), gy, 1, act.alpha.detach().float(), act.beta.detach().float(), True)
+    assert rel(dx, dx_ref) < 1e-5 and rel(da, da_ref) < 1e-4 and rel(db, db_ref) < 1e-4
+    s = conv_train.channel_sum(gy)
+    assert rel(s, gy.sum(dim=(0, 2))) < 1e-5
+
+
+def test_chunked_encode_with_enable_grad_is_differentiable(dev):
+    """AutoencoderPretransform(enable_grad) + chunked=True: the latents must carry a graph (the reference's slice-assign loop is
+    differentiable, autoencoders.py:468-494) and equal the kernel-pasted ones"""
+    from stable_audio_tools.models.autoencoders import AudioAutoencoder, OobleckDecoder, OobleckEncoder
+    torch.manual_seed(0)
+    enc = OobleckEncoder(in_channels=2, channels=8, latent_dim=4, c_mults=[1, 2], strides=[2, 4], use_snake=True)
+    dec = OobleckDecoder(out_channels=2, channels=8, latent_dim=4, c_mults=[1, 2], strides=[2, 4], use_snake=True)
+    ae = AudioAutoencoder(enc, dec, latent_dim=4, downsampling_ratio=8, sample_rate=16000, io_channels=2).to(dev)
+    wav = torch.randn(2, 2, 8 * 40, device=dev)
+    with torch.no_grad():
+        want = ae.encode_audio(wav, chunked=True, chunk_size=16, overlap=4)
+    got = ae.encode_audio(wav, chunked=True, chunk_size=16, overlap=4)
+    assert got.requires_grad and rel(got, want) < 1e-5
+    got.square().mean().backward()
+    gn = [p.grad.norm().item() for p in ae.encoder.parameters() if p.grad is not None]
+    assert gn and all(v == v for v in gn) and max(gn) > 0

@@ -1,11 +1,16 @@
 """profiles/r01_pmc_mfma_util.md from `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py
 --steps 2 --warmup 1 --no-cpu-baseline`.   python tools/pmc_mfma_summary.py DIR"""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 d = sys.argv[1]
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt, dur = collections.Counter(), collections.defaultdict(float)
-for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])):
+files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+if not files:
+    sys.exit(f"no counter_collection.csv under {d}")
+if len(files) > 1:      # gpurun MERGES gpurun_out/ back: older passes pile up locally - the newest one is this run's
+    print(f"note: {len(files)} counter files under {d}; using the newest ({files[-1]})", file=sys.stderr)
+for r in csv.DictReader(open(files[-1])):
     name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":

@@ -1,12 +1,17 @@
 """profiles/r01_pmc_hbm_traffic_b256.json + profiles/traffic_r01.json (what bench.py puts into roofline.traffic) from two
 rocprofv3 passes over `tools/bench_one_step.py 256 1`: --kernel-trace --pmc FETCH_SIZE and --kernel-trace --pmc WRITE_SIZE
 (separate passes).  python tools/pmc_traffic_summary.py FETCH_DIR WRITE_DIR"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, subprocess, sys
 
 
 def load(d, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])):
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    if not files:
+        sys.exit(f"no counter_collection.csv under {d}")
+    if len(files) > 1:      # gpurun MERGES gpurun_out/ back: older passes pile up locally - the newest one is this run's
+        print(f"note: {len(files)} counter files under {d}; using the newest ({files[-1]})", file=sys.stderr)
+    for r in csv.DictReader(open(files[-1])):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
@@ -34,6 +39,20 @@ for k, (n, fs) in sorted(f.items(), key=lambda kv: -kv[1][1]):
         key = "%s<%d,%d,%d%s>" % (m.group(1), m.group(2) == "true", m.group(3) == "true", m.group(4) == "true",
                                   ",glu%s" % glu if glu and glu != "0" else "")
         short[key] = int((2 * fs + ws) * 1024 / n)
+# which code the counters were collected from: the kernel-source hash written on the box next to the passes, and the commit
+# checked out when the summary was made (with a flag if the tree's kernel sources no longer hash to the run's stamp)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kalle_audio_amd.build import source_stamp  # noqa: E402
+stamp_file = os.path.join(os.path.dirname(os.path.normpath(sys.argv[1])), "source_stamp.txt")
+run_stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+except OSError:
+    commit = None
+short["_source"] = {"csrc_sha16": run_stamp, "commit_at_publish": commit, "tree_matches_run": run_stamp == source_stamp(),
+                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/bench_one_step.py 256 1"}
+full["_source"] = short["_source"]
 json.dump(full, open(f"profiles/{TAG}_pmc_hbm_traffic_b256.json", "w"), indent=1)
 json.dump(short, open(f"profiles/traffic_{TAG}.json", "w"), indent=1)
 print(json.dumps(short, indent=1))

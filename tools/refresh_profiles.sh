@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd $R
+python -c "from kalle_audio_amd.build import source_stamp; print(source_stamp())" > $O/source_stamp.txt
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log
 timeout -k 10 600 python bench.py 2> $O/default.err | tail -n 1 > $O/default.json || exit 1
 cd /tmp && export TMPDIR=/tmp
