@@ -89,6 +89,12 @@ int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int
  * split-K factor, for 5 bits 8-11 / 12-15 = tile rows / columns in units of 64, bits 16.. = K slices */
 int kalle_gemm_last_plan(void);
 
+/* diagnostics (tools/gemm_stamps.py), never set by the product path: with a non-NULL device buffer of
+ * [workgroups][2][8] uint64 the 256x256 kernel's wave 0 / wave 7 leave s_memrealtime stamps (100 MHz) at: 0 entry, 1 first
+ * K-tile landed, 2 main loop done, 3 epilogue barrier passed, 4 stores issued, 5 stores acknowledged (an extra wait that only
+ * exists while the buffer is set).  NULL switches it off again.  Process-wide. */
+int kalle_gemm_debug_stamps(void* buf);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (bias-less gamma, eps 1e-5) with optional adaLN modulation - one wavefront per row.
  *   y = ((x-mean)*rstd*gamma + beta) * (1 + scale[b]) + shift[b]        (transformer.py:173-192, 660-665, 677-679)
@@ -460,7 +466,8 @@ int kalle_weight_norm_bwd(const float* dw, const float* v, const float* g, float
 
 /* anti-aliased periodic activation (alias-free-torch `Activation1d`, third-party, used by the mel-VAE decoder,
  * backup/flows.py:266-279,452-456): 2x kaiser-sinc FIR upsample (12 taps, replicate pad) -> x + sin^2(x a)/(b+1e-9)
- * -> 2x FIR low-pass downsample.  x, y: (B, C, L) fp32 or bf16; filter12: the 12 fp32 taps. */
+ * -> 2x FIR low-pass downsample.  x, y: (B, C, L) fp32 or bf16; filter12: the 12 fp32 taps.  alpha == beta == NULL: ELU in
+ * place of the snake (Oobleck units built with antialias_activation=True and use_snake=False, autoencoders.py:24-37). */
 int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* filter12, const float* alpha, const float* beta,
                     int logscale, int B, int C, int L, void* stream);
 /* standalone SnakeBeta: y = x + sin^2(x e^alpha) / (e^beta + 1e-9)     (blocks.py:301-339) */

@@ -18,7 +18,7 @@ def install():
     for sub in ("models", "models.factory", "models.transformer", "models.dit", "models.diffusion", "models.blocks",
                 "models.autoencoders", "models.bottleneck", "models.pretransforms", "models.utils", "training",
                 "training.diffusion", "training.losses", "training.losses.losses", "training.utils", "inference",
-                "inference.sampling", "inference.generation"):
+                "inference.sampling", "inference.generation", "inference.utils"):
         sys.modules["stable_audio_tools." + sub] = importlib.import_module(f"{__name__}.stable_audio_tools.{sub}")
     # the reference's top-level modules on the path: the task models (train_offline.py:19 `from model_sigmaVAE import
     # Llasa`, train.py:24 `from model import Llasa`) and the mel-VAE (infer_0828_sigma.py:18 `from flows import BigVGANFlowVAE`)

@@ -859,9 +859,9 @@ __global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, 
     // xs[j] = x_pad[i0 + j] (replicate padding folded in);  as[j] = act(u[clamp(2 t0 - 5 + j)])
     __shared__ __attribute__((aligned(16))) float xs[A1_T + 16];
     __shared__ __attribute__((aligned(16))) float as[2 * A1_T + 16];
-    const int row = blockIdx.y;                     // b * C + c
+    const int row = blockIdx.x;                     // b * C + c (rows on grid x: B * C may exceed grid y's 65535)
     const int c = row % C;
-    const int t0 = blockIdx.x * A1_T;
+    const int t0 = blockIdx.y * A1_T;
     const int64_t base = (int64_t)row * L;
     float f[12];
 #pragma unroll
@@ -873,8 +873,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, 
         xs[j] = ld1<F32>(x, base + xi);
     }
     __syncthreads();
-    float a = alpha[c], b = beta[c];
-    if (logscale) { a = __expf(a); b = __expf(b); }
+    // alpha == NULL: ELU in place of the snake (Oobleck units with antialias_activation and use_snake=False, autoencoders.py:24-37)
+    const bool elu = alpha == nullptr;
+    float a = elu ? 0.f : alpha[c], b = elu ? 1.f : beta[c];
+    if (logscale && !elu) { a = __expf(a); b = __expf(b); }
     const float inv_b = 1.f / (b + 1e-9f);
     // each thread produces 8 consecutive as[] slots (+ the 12-slot tail by the first threads) from a register window of x
     for (int j0 = 8 * threadIdx.x; j0 < 2 * A1_T + 12; j0 += 8 * 256) {
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, 
                 u = 2.f * uu;
             }
             const float sn = fast_sin(u * a);
-            as[j] = u + inv_b * sn * sn;
+            as[j] = elu ? (u > 0.f ? u : __expf(u) - 1.f) : u + inv_b * sn * sn;
         }
     }
     __syncthreads();
@@ -935,9 +937,10 @@ __global__ __launch_bounds__(256) void act1d_kernel(const void* __restrict__ x, 
 
 extern "C" int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* filter12, const float* alpha,
                                const float* beta, int logscale, int B, int C, int L, void* stream) {
-    if (!x || !y || !filter12 || !alpha || !beta || B <= 0 || C <= 0 || L <= 0 || (int64_t)B * C > 65535)
+    if (!x || !y || !filter12 || ((alpha == nullptr) != (beta == nullptr)) || B <= 0 || C <= 0 || L <= 0 ||
+        (int64_t)B * C > 0x7fffffff || (L + A1_T - 1) / A1_T > 65535)
         return KALLE_ERR_ARG;
-    dim3 grid((L + A1_T - 1) / A1_T, B * C), block(256);
+    dim3 grid(B * C, (L + A1_T - 1) / A1_T), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == KALLE_F32) KALLE_LAUNCH((act1d_kernel<true>), grid, block, 0, st, x, y, filter12, alpha, beta, logscale, C, L);
     else KALLE_LAUNCH((act1d_kernel<false>), grid, block, 0, st, x, y, filter12, alpha, beta, logscale, C, L);

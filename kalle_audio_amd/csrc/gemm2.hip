@@ -179,23 +179,41 @@ struct Reader {
     }
 };
 
+// diagnostics: wave 0 / wave 7 of a workgroup leave a time stamp (constant 100 MHz counter, comparable across CUs)
+__device__ __forceinline__ void gemm_stamp(const GemmParams& p, int wave, int lane, int idx, int slot = -1) {
+    if (p.stamps && (wave == 0 || wave == 7) && lane == 0)
+        p.stamps[((int64_t)(slot < 0 ? (int)blockIdx.x : slot) * 2 + (wave ? 1 : 0)) * 8 + idx] = __builtin_amdgcn_s_memrealtime();
+}
+
 // ---- epilogue: per wave, one 16 x 64 fp32 piece at a time through a wave-private LDS patch ---------------------------
-template <bool C_F32, int TM, int GLU = 0>
-__device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane,
-                                              int row0, int col0) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // all waves are done with the pipeline stages
-    constexpr int PLD = 68;         // floats per patch row (64 + 4 pad)
-    float* patch = reinterpret_cast<float*>(smem) + wave * (16 * PLD);
+// What the in-kernel stamps of round 3 showed (tools/gemm_stamps.py, all 256 CUs in their epilogue at once): the STORE side is
+// absorbed by L2 / Infinity Cache at fabric speed and is bound by the number of store instructions (8-byte bf16 stores: 128 KB
+// in 8.8 us; 16-byte stores: 192 KB in 5.3 us), the LOAD side (fp32 residual, saved SwiGLU pre-activations: 256 KB per tile from
+// HBM) by the bytes a wave keeps in flight - one 16-row piece ahead is 4 KB per wave = 16 GB/s per CU against ~2 us of loaded
+// latency - or so it seemed: fetching THREE pieces ahead (first loads before the hand-over barrier) changed nothing (fused
+// SwiGLU backward 20.5 -> 18.4 us, fp32 residual 20.0 -> 22.3 us per tile), because with every CU in its epilogue at once the
+// 64 MB read + 64 MB written per round ARE the HBM's 6.5-7 TB/s for those 18-20 us.  So: every output leaves in 16-byte stores
+// (bf16 outputs 8.8 -> 6.4 us per tile), and the epilogue operands stay one piece ahead (EPI_DEPTH; deeper only costs registers).
+constexpr int EPI_DEPTH = 1;
+
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// patch: 16 rows x 64 floats per wave, NO padding (8 waves = exactly the 32 KiB the two 64-KiB stages leave of a CU's 160 KiB, so
+// the persistent 256 x 256 kernel can refill the stages while the epilogue runs); 16-byte chunk c of row r sits at chunk
+// c ^ (r & 1): conflict-free for the fp32 (rows g + 4i, chunk li) and the bf16 (row lane >> 3, chunks 2j, 2j + 1) read patterns
+__device__ __forceinline__ int pidx(int r, int c) { return r * 64 + (c ^ ((r & 1) << 2)); }
+
+template <bool C_F32, int TM, int GLU = 0, typename Hook = NoHook>
+__device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[TM][4], char* patch_base, int wave, int lane,
+                                              int row0, int col0, Hook after_barrier = Hook{}, int stamp_slot = -1) {
+    constexpr int DEPTH = EPI_DEPTH < TM ? EPI_DEPTH : TM;
+    float* patch = reinterpret_cast<float*>(patch_base) + wave * (16 * 64);
     const int g = lane >> 4, li = lane & 15;
-    float sx[8], sg[8];             // GLU backward: bias-gradient partial sums of this lane's 8 columns
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sg[e] = 0.f; }
-    // The residual (the fp32 stream, updated in place: it aliases C as far as the compiler can tell) is fetched one 16-row
-    // piece AHEAD of the stores: left inside the store loop every one of a wave's 32 load -> add -> store chains exposes a
-    // global-load latency (the pieces are disjoint rows, so reading piece mt+1 before piece mt is stored is safe).
-    const bool pre_res = GLU == 0 && !p.atomic && p.residual != nullptr;
-    f32x4 rnext[4], rcur[4];
+    // The residual (the fp32 stream, updated in place: it aliases C as far as the compiler can tell) is fetched DEPTH 16-row
+    // pieces AHEAD of the stores: left inside the store loop every one of a wave's 32 load -> add -> store chains exposes a
+    // global-load latency (the pieces are disjoint rows, so reading a later piece before an earlier one is stored is safe).
+    const bool pre_res = C_F32 && GLU == 0 && !p.atomic && p.residual != nullptr;
+    f32x4 rbuf[DEPTH][4];
     auto load_res = [&](int mt, f32x4 (&rv)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -204,26 +222,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             if (gm < p.M && gn < p.N) rv[i] = *reinterpret_cast<const f32x4*>(p.residual + gemm_crow(p, gm) * p.ldr + gn);
         }
     };
-    if (pre_res) load_res(0, rnext);
-    // the bias of a lane's columns is the same for every piece: loaded once (inside the loop each load sits behind the
-    // previous piece's stores, which may alias it for all the compiler knows)
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bx[8], bg[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { bx[e] = 0.f; bg[e] = 0.f; }
-    if (p.bias) {
-        if constexpr (GLU == 1) {
-            const int j0 = col0 + (lane & 3) * 8;
-            if (j0 < p.glu_inner) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { bx[e] = p.bias[j0 + e]; bg[e] = p.bias[p.glu_inner + j0 + e]; }
-            }
-        } else if constexpr (GLU == 0) {
-            if (!p.atomic && col0 + 4 * li < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4 * li);
-        }
-    }
-    // fused SwiGLU backward: the saved pre-activations h (x | gate) of a piece, fetched one piece ahead like the residual
-    i32x4 hnext[2][2], hcur[2][2];
+    // fused SwiGLU backward: the saved pre-activations h (x | gate) of a piece, fetched ahead like the residual
+    i32x4 hbuf[DEPTH][2][2];
     auto load_h = [&](int mt, i32x4 (&hv)[2][2]) {
         const int c8 = (lane & 7) * 8, j0 = col0 + c8;
 #pragma unroll
@@ -238,23 +238,65 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         }
     };
-    if constexpr (GLU == 2) load_h(0, hnext);
+    // (the LDS-DMA of the main loop was waited for at its last hand-over: nothing of the pipeline is outstanding here - only
+    // the fragment reads must have returned)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all waves are done with the pipeline stages
+    after_barrier();                // (persistent kernel: the stage of the last K-tile is free now - DMA of the next tile's K-tile 1)
+    gemm_stamp(p, wave, lane, 3, stamp_slot);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if constexpr (GLU == 2) load_h(d, hbuf[d]);
+        if (pre_res) load_res(d, rbuf[d]);
+    }
+    f32x2 sx2[4], sg2[4];           // GLU backward: bias-gradient partial sums of this lane's 8 columns (as pairs)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sx2[e] = f32x2{0.f, 0.f}; sg2[e] = f32x2{0.f, 0.f}; }
+    // the bias of a lane's columns is the same for every piece: loaded once (inside the loop each load sits behind the
+    // previous piece's stores, which may alias it for all the compiler knows)
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, bias8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float bx[8], bg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bx[e] = 0.f; bg[e] = 0.f; }
+    if (p.bias) {
+        if constexpr (GLU == 1) {
+            const int j0 = col0 + (lane & 3) * 8;
+            if (j0 < p.glu_inner) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bx[e] = p.bias[j0 + e]; bg[e] = p.bias[p.glu_inner + j0 + e]; }
+            }
+        } else if constexpr (GLU == 0) {
+            if constexpr (C_F32) {
+                if (!p.atomic && col0 + 4 * li < p.N) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4 * li);
+            } else {
+                const int gn = col0 + 8 * (lane & 7);
+                if (gn < p.N) {
+                    bias8[0] = *reinterpret_cast<const f32x4*>(p.bias + gn);
+                    bias8[1] = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
+        const int slot = mt % DEPTH;
+        // this piece's operands move to `cur`, their slot is refilled right away: the loads run under this piece's work
+        f32x4 rcur[4];
+        i32x4 hcur[2][2];
         if constexpr (GLU == 2) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) { hcur[half][0] = hnext[half][0]; hcur[half][1] = hnext[half][1]; }
-            if (mt + 1 < TM) load_h(mt + 1, hnext);
+            for (int half = 0; half < 2; ++half) { hcur[half][0] = hbuf[slot][half][0]; hcur[half][1] = hbuf[slot][half][1]; }
+            if (mt + DEPTH < TM) load_h(mt + DEPTH, hbuf[slot]);
         }
         if (pre_res) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
-            if (mt + 1 < TM) load_res(mt + 1, rnext);
+            for (int i = 0; i < 4; ++i) rcur[i] = rbuf[slot][i];
+            if (mt + DEPTH < TM) load_res(mt + DEPTH, rbuf[slot]);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) patch[(4 * g + r) * PLD + 16 * nt + li] = acc[mt][nt][r];
+            for (int r = 0; r < 4; ++r) patch[pidx(4 * g + r, 16 * nt + li)] = acc[mt][nt][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int rbase = row0 + 16 * mt;
         if constexpr (GLU == 1) {
@@ -264,7 +306,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             if (gm < p.M && j0 < p.glu_inner) {
                 float xv[8], gv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { xv[e] = patch[r * PLD + c8 + e]; gv[e] = patch[r * PLD + 32 + c8 + e]; }
+                for (int e = 0; e < 8; ++e) { xv[e] = patch[pidx(r, c8 + e)]; gv[e] = patch[pidx(r, 32 + c8 + e)]; }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xv[e] += bx[e]; gv[e] += bg[e]; }
                 i32x4 hx, hg, av;
@@ -283,7 +325,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 *reinterpret_cast<i32x4*>(static_cast<bf16_t*>(p.glu_aux) + (int64_t)gm * p.glu_inner + j0) = av;
             }
         } else if constexpr (GLU == 2) {
-            // fused SwiGLU backward: acc = d(act)[m][j]; reads h, writes dh = (dact*silu(g), dact*x*silu'(g)), sums db
+            // fused SwiGLU backward: acc = d(act)[m][j]; reads h, writes dh = (dact*silu(g), dact*x*silu'(g)), sums db.
+            // The stamps put this epilogue at 21 us per tile whatever the other CUs do (de-phased workgroups, deeper operand
+            // prefetch: no change) - a good half of it is this arithmetic, 16 elements per lane per piece.  It runs on PAIRS:
+            // f32x2 arithmetic lowers to v_pk_mul / v_pk_fma / v_pk_add_f32 (two elements per instruction; only v_exp / v_rcp stay
+            // scalar), with s = sigmoid(g), t = g s:  dx = d t,  dg = d x (s + t (1 - s)).
             const int c8 = (lane & 7) * 8, j0 = col0 + c8;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -291,25 +337,31 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int gm = rbase + r;
                 if (gm < p.M && j0 < p.glu_inner) {
                     const i32x4 xv = hcur[half][0], gv = hcur[half][1];
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(patch + pidx(r, c8));
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(patch + pidx(r, c8 + 4));
+                    const float dv[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
                     i32x4 ox, og;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x[2] = {bf16lo((uint32_t)xv[e]), bf16hi((uint32_t)xv[e])};
-                        const float gg[2] = {bf16lo((uint32_t)gv[e]), bf16hi((uint32_t)gv[e])};
+                        const f32x2 x = {bf16lo((uint32_t)xv[e]), bf16hi((uint32_t)xv[e])};
+                        const f32x2 gg = {bf16lo((uint32_t)gv[e]), bf16hi((uint32_t)gv[e])};
                         // the unfused path rounds dact to bf16 between the GEMM and the activation backward
-                        const float d[2] = {bf16_to_f32(f32_to_bf16(patch[r * PLD + c8 + 2 * e] * p.alpha)),
-                                            bf16_to_f32(f32_to_bf16(patch[r * PLD + c8 + 2 * e + 1] * p.alpha))};
-                        float dx[2], dg[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const float sgm = sigmoidf_(gg[q]);
-                            dx[q] = d[q] * gg[q] * sgm;
-                            dg[q] = d[q] * x[q] * sgm * (1.f + gg[q] * (1.f - sgm));
-                        }
+                        const uint32_t dr = pack_bf16x2(dv[2 * e] * p.alpha, dv[2 * e + 1] * p.alpha);
+                        const f32x2 d = {bf16lo(dr), bf16hi(dr)};
+                        const f32x2 ng = gg * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+                        const f32x2 en = {__builtin_amdgcn_exp2f(ng[0]), __builtin_amdgcn_exp2f(ng[1])};
+                        const f32x2 den = en + f32x2{1.f, 1.f};
+                        const f32x2 sgm = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                        const f32x2 t = gg * sgm;
+                        const f32x2 dx = d * t;
+                        const f32x2 w = __builtin_elementwise_fma(t, f32x2{1.f, 1.f} - sgm, sgm);
+                        const f32x2 dg = (d * x) * w;
                         ox[e] = (int)pack_bf16x2(dx[0], dx[1]);
                         og[e] = (int)pack_bf16x2(dg[0], dg[1]);
-                        sx[2 * e] += bf16lo((uint32_t)ox[e]); sx[2 * e + 1] += bf16hi((uint32_t)ox[e]);
-                        sg[2 * e] += bf16lo((uint32_t)og[e]); sg[2 * e + 1] += bf16hi((uint32_t)og[e]);
+                        const f32x2 rx = {bf16lo((uint32_t)ox[e]), bf16hi((uint32_t)ox[e])};   // bias gradient = column sums of the
+                        const f32x2 rg = {bf16lo((uint32_t)og[e]), bf16hi((uint32_t)og[e])};   // STORED (bf16) dh, as the unfused kernel
+                        sx2[e] += rx;
+                        sg2[e] += rg;
                     }
                     bf16_t* dp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
                     *reinterpret_cast<i32x4*>(dp + j0) = ox;
@@ -323,15 +375,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             for (int r = 0; r < 16; ++r) {
                 const int gm = rbase + r;
                 if (gm < p.M && gn < p.N)
-                    atomicAdd(reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn, patch[r * PLD + lane] * p.alpha);
+                    atomicAdd(reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn, patch[pidx(r, lane)] * p.alpha);
             }
-        } else {
+        } else if constexpr (C_F32) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = g + 4 * i;
                 const int gm = rbase + r, gn = col0 + 4 * li;
                 if (gm >= p.M || gn >= p.N) continue;
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + r * PLD + 4 * li);
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(patch + pidx(r, 4 * li));
                 float v[4] = {pv[0], pv[1], pv[2], pv[3]};
                 const int64_t crow = gemm_crow(p, gm);
                 gemm_epilogue4(p, gm, gn, crow, v, false, &bias4);
@@ -339,20 +391,33 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += rcur[i][j];
                 }
-                if constexpr (C_F32) {
-                    float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
-                    if (p.accumulate) {
-                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
+                float* cp = reinterpret_cast<float*>(p.C) + crow * p.ldc + gn;
+                if (p.accumulate) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += c0[j];
-                    }
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-                    i32x2 o;
-                    o[0] = (int)pack_bf16x2(v[0], v[1]);
-                    o[1] = (int)pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<i32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
+                    for (int j = 0; j < 4; ++j) v[j] += c0[j];
                 }
+                *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+            // bf16 output: a lane owns 8 consecutive columns of a row -> ONE 16-byte store (8 lanes = a row's 128 bytes)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = (lane >> 3) + 8 * half;
+                const int gm = rbase + r, gn = col0 + 8 * (lane & 7);
+                if (gm >= p.M || gn >= p.N) continue;
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(patch + pidx(r, 8 * (lane & 7)));
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(patch + pidx(r, 8 * (lane & 7) + 4));
+                float v0[4] = {p0[0], p0[1], p0[2], p0[3]}, v1[4] = {p1[0], p1[1], p1[2], p1[3]};
+                const int64_t crow = gemm_crow(p, gm);
+                gemm_epilogue4(p, gm, gn, crow, v0, true, &bias8[0]);
+                gemm_epilogue4(p, gm, gn + 4, crow, v1, true, &bias8[1]);
+                i32x4 o;
+                o[0] = (int)pack_bf16x2(v0[0], v0[1]);
+                o[1] = (int)pack_bf16x2(v0[2], v0[3]);
+                o[2] = (int)pack_bf16x2(v1[0], v1[1]);
+                o[3] = (int)pack_bf16x2(v1[2], v1[3]);
+                *reinterpret_cast<i32x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = o;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch reads done before the next piece overwrites it
@@ -360,6 +425,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
     if constexpr (GLU == 2) {
         if (p.glu_dbias) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row-lanes, then 16 atomics from lanes 0-7
+            float sx[8], sg[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sx[2 * e] = sx2[e][0]; sx[2 * e + 1] = sx2[e][1]; sg[2 * e] = sg2[e][0]; sg[2 * e + 1] = sg2[e][1]; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -374,6 +442,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
             }
         }
+    }
+    if (p.stamps) {
+        gemm_stamp(p, wave, lane, 4, stamp_slot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gemm_stamp(p, wave, lane, 5, stamp_slot);
     }
 }
 
@@ -708,14 +781,39 @@ int launch2(const GemmParams& p, hipStream_t st) {
 // a wave reads the 12 fragments of a 32-deep k-step, waits, issues its 32 MFMAs; latency is covered by its SIMD
 // partner, which runs half a phase apart (second half of the workgroup defers the last MFMA block of a K-tile past
 // the barrier).  Per MFMA this tile needs 25 % fewer LDS reads, 33 % fewer DMA pieces and L2->LDS bytes than 256x128.
+constexpr int GEMM3_LDS = 2 * (256 + 256) * 128 + 8 * 16 * 64 * 4;      // two 64-KiB stages + the epilogue patches = 160 KiB
+
+// compute units of the current device (cached per device ordinal)
+static int kalle_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    v &= ~7;                                // a multiple of 8: a workgroup's tiles stay on one XCD's run of the raster
+    if (v < 8) v = 8;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 #define MFMA32(FA, FB)                                                                                         \
     _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)          \
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
                                                               __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
 
-// one 256 x 256 output tile over K-tiles [kt0, kt0 + nk) of problem `p` (shared by the plain and the grouped kernel)
-template <bool A_KM, bool B_KM, bool C_F32, int GLU>
-__device__ __forceinline__ void gemm3_tile(const GemmParams& p, int tm, int tn, int kt0, int nk) {
+// 256 x 256 output tiles `tile0, tile0 + tstride, ...` (< tile_end; ids in the XCD-aware grouped raster, or plain raster for the
+// grouped launch) over K-tiles [kt0, kt0 + nk) of problem `p` - shared by the plain, the persistent and the grouped kernel.
+// PERSISTENT form (tstride > 0, one workgroup per CU walks its tiles): what the in-kernel stamps showed per K = 1536 tile - 1.6-2.4 us
+// from entry to the first K-tile landed, ~1 us between a workgroup's exit and its successor's entry - is taken off the critical
+// path: the next tile's K-tile 0 is requested at the START of the last K-tile of the current one (into the stage that fell free
+// at the previous hand-over), its K-tile 1 right after the epilogue's barrier (into the stage of the last K-tile), and the
+// epilogue's LDS patch lives in the 32 KiB the two stages leave free.  The stores of the epilogue are younger than those DMA
+// requests in the wave's VMEM queue, so the next tile starts with vmcnt(0) (stores are acknowledged ~0.2 us after issue).
+template <bool A_KM, bool B_KM, bool C_F32, int GLU, bool XCD_RASTER, bool PERSIST>
+__device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int tstride, int tile_end, int ntiles_raster, int kt0,
+                                            int nk) {
     const int kvalid = p.K % BK2;                                               // ragged last K-tile (0: none)
     const int tail_t = kvalid ? (p.K + BK2 - 1) / BK2 - 1 - kt0 : -1;           // its index inside [0, nk)
     constexpr int WN = 4, TM = 8, NW = 8;
@@ -727,109 +825,183 @@ __device__ __forceinline__ void gemm3_tile(const GemmParams& p, int tm, int tn, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    f32x4 acc[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    const int arow = wm * 128, bcol = wn * 64;
     Loader<A_KM, BM, NW> la;
     Loader<B_KM, BN, NW> lb;
-    la.init(p.A, p.lda, p.M, m0, kt0 * BK2, wave, lane);
-    lb.init(p.B, p.ldb, p.N, n0, kt0 * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
-    const int arow = wm * 128, bcol = wn * 64;
     Reader<A_KM, BM> ra;
     Reader<B_KM, BN> rb;
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
-
-    la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
-    lb.issue_at(smem + A_BYTES, wave, lane, 0, tail_t, kvalid);
-    if (nk > 1) {
-        la.issue_at(smem + STAGE, wave, lane, 1, tail_t, kvalid);
-        lb.issue_at(smem + STAGE + A_BYTES, wave, lane, 1, tail_t, kvalid);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 + 4 DMA pieces per tile per wave
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
-    i32x4 fa[8], fb[4];
-    unsigned so_cur = 0;
-    int kt = 0;
     const bool late = wave >= NW / 2;     // the staggered half
     if (late) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every issue arbitration by age otherwise
-    // prologue of the software pipeline: k-step 0 of tile 0
-    ra.template read<0, 8>(0, fa);
-    rb.template read<0, 4>(0, fb);
 
-    auto iteration = [&](auto issue_c, auto next_c) {
-        constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
-        // k-step 0 of this tile is in flight / landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        MFMA32(fa, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        ra.template read<1, 8>(so_cur, fa);
-        rb.template read<1, 4>(so_cur, fb);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last reads of this stage are done
-        __builtin_amdgcn_sched_barrier(0);
-        if (!late) {
-            MFMA32(fa, fb);
-            __builtin_amdgcn_sched_barrier(0);
+    auto coords = [&](int tile, int& tm, int& tn) {
+        if constexpr (XCD_RASTER) gemm_tile_coords(tile, ntiles_raster, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        else gemm_tile_coords_plain(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    };
+    auto init_loaders = [&](int tm, int tn, int kt_first) {      // source pointers of K-tile `kt_first` of this workgroup's range
+        la.init(p.A, p.lda, p.M, tm * BM, (kt0 + kt_first) * BK2, wave, lane);
+        lb.init(p.B, p.ldb, p.N, tn * BN, (kt0 + kt_first) * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
+    };
+    if constexpr (PERSIST) {
+        if (p.dephase_ticks > 0 && ((blockIdx.x >> 3) & 1)) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)p.dephase_ticks;
+            while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(32);
         }
-        // hand-over: everybody's DMA of tile kt+1 has landed, everybody is done reading this stage
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bool prefetched = false;              // K-tiles 0 (and 1) of `tile` were requested by the previous tile's tail
+    unsigned s0 = 0;                      // stage (byte offset) that holds K-tile 0 of `tile`
+
+    for (int tile = tile0; tile < tile_end; tile += tstride) {
+        int tm, tn;
+        coords(tile, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        const bool has_next = PERSIST && tile + tstride < tile_end;
+        gemm_stamp(p, wave, lane, 0, tile);
+        f32x4 acc[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (!prefetched) {
+            init_loaders(tm, tn, 0);
+            la.issue_at(smem, wave, lane, 0, tail_t, kvalid);
+            lb.issue_at(smem + A_BYTES, wave, lane, 0, tail_t, kvalid);
+            s0 = 0;
+            if (nk > 1) {
+                la.issue_at(smem + STAGE, wave, lane, 1, tail_t, kvalid);
+                lb.issue_at(smem + STAGE + A_BYTES, wave, lane, 1, tail_t, kvalid);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 + 4 DMA pieces per tile per wave
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if constexpr (PERSIST) {
+            init_loaders(tm, tn, nk > 1 ? 2 : 1);                  // (K-tiles 0 and 1 are on their way)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // both prefetched K-tiles + the previous epilogue's stores
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (late) {
+        gemm_stamp(p, wave, lane, 1, tile);
+
+        i32x4 fa[8], fb[4];
+        unsigned so_cur = s0;
+        int kt = 0;
+        // prologue of the software pipeline: k-step 0 of tile 0
+        ra.template read<0, 8>(so_cur, fa);
+        rb.template read<0, 4>(so_cur, fb);
+
+        auto iteration = [&](auto issue_c, auto next_c) {
+            constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+            // k-step 0 of this tile is in flight / landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             MFMA32(fa, fb);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+2 into it
-            la.issue_at(smem + so_cur, wave, lane, kt + 2, tail_t, kvalid);
-            lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + 2, tail_t, kvalid);
-        }
-        so_cur ^= STAGE;
-        if constexpr (NEXT) {
-            ra.template read<0, 8>(so_cur, fa);
-            rb.template read<0, 4>(so_cur, fb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
+            ra.template read<1, 8>(so_cur, fa);
+            rb.template read<1, 4>(so_cur, fb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last reads of this stage are done
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late) {
+                MFMA32(fa, fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // hand-over: everybody's DMA of tile kt+1 has landed, everybody is done reading this stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) {
+                MFMA32(fa, fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+2 into it
+                la.issue_at(smem + so_cur, wave, lane, kt + 2, tail_t, kvalid);
+                lb.issue_at(smem + so_cur + A_BYTES, wave, lane, kt + 2, tail_t, kvalid);
+            }
+            so_cur ^= STAGE;
+            if constexpr (NEXT) {
+                ra.template read<0, 8>(so_cur, fa);
+                rb.template read<0, 4>(so_cur, fb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the last K-tile: no hand-over (the epilogue's barrier follows)
+        auto last_iteration = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA32(fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            ra.template read<1, 8>(so_cur, fa);
+            rb.template read<1, 4>(so_cur, fb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA32(fa, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
 #pragma unroll 1
-    for (; kt + 2 < nk; ++kt) iteration(T_{}, T_{});
-    if (kt + 1 < nk) { iteration(F_{}, T_{}); ++kt; }
-    iteration(F_{}, F_{});
+        for (; kt + 2 < nk; ++kt) iteration(T_{}, T_{});
+        if (kt + 1 < nk) { iteration(F_{}, T_{}); ++kt; }
+        // (register allocation, not timing, picks the form: without the hand-over barrier the compiler starts the epilogue's set-up
+        // under the last MFMAs - 27 more VGPRs in the one-tile kernels, 33 spilled in the fused SwiGLU backward)
+        if constexpr (!PERSIST || GLU == 2) iteration(F_{}, F_{});
+        else last_iteration();
+        gemm_stamp(p, wave, lane, 2, tile);
 
-    wave_epilogue<C_F32, TM, GLU>(p, acc, smem, wave, lane, m0 + arow, GLU == 1 ? tn * 128 + wn * 32 : n0 + bcol);
+        // Behind the epilogue's barrier both stages are free: request the next tile's K-tiles 0 and 1 there.  The loaders are
+        // set up for these two requests only and die with them (kept alive across the epilogue they cost 16 VGPRs and spills);
+        // the next tile re-initialises them two K-tiles further on.
+        const unsigned s_last = so_cur;                 // stage of the last K-tile -> next K-tile 1; the other one -> next K-tile 0
+        auto hook = [&]() {
+            if constexpr (!PERSIST) return;
+            if (has_next) {
+                int ntm, ntn;
+                coords(tile + tstride, ntm, ntn);
+                init_loaders(ntm, ntn, 0);
+                la.issue_at(smem + (s_last ^ STAGE), wave, lane, 0, tail_t, kvalid);
+                lb.issue_at(smem + (s_last ^ STAGE) + A_BYTES, wave, lane, 0, tail_t, kvalid);
+                if (nk > 1) {
+                    la.issue_at(smem + s_last, wave, lane, 1, tail_t, kvalid);
+                    lb.issue_at(smem + s_last + A_BYTES, wave, lane, 1, tail_t, kvalid);
+                }
+            }
+        };
+        wave_epilogue<C_F32, TM, GLU>(p, acc, smem + 2 * STAGE, wave, lane, m0 + arow, GLU == 1 ? tn * 128 + wn * 32 : n0 + bcol,
+                                      hook, tile);
+        prefetched = has_next;
+        s0 = s_last ^ STAGE;
+        if constexpr (!PERSIST) break;
+    }
 }
 
+// Two forms, one per instantiation (both in one kernel cost 40 VGPRs and spills): the weight-gradient layout (k-major A) is the only
+// one that is ever cut along K - one workgroup per (tile, K slice), uniform or mixed split; every other layout runs whole-K tiles
+// on the persistent form.
 template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
     const int nk_all = (p.K + BK2 - 1) / BK2;
-    int tm, tn, kt0, nk;
-    if (p.mix_na >= 0) {
-        // mixed split-K: 1-D grid; blocks [0, na * sa) = tiles [0, na) x sa slices (tile fastest), then the other tiles x (sa + 1)
-        const int ntiles = p.tiles_m * p.tiles_n, na = p.mix_na, sa = p.mix_sa;
-        int bid = blockIdx.x, tile, slice, per;
-        if (bid < na * sa) { tile = bid % na; slice = bid / na; per = (nk_all + sa - 1) / sa; }
-        else { bid -= na * sa; const int nb = ntiles - na; tile = na + bid % nb; slice = bid / nb; per = (nk_all + sa) / (sa + 1); }
-        gemm_tile_coords(tile, ntiles, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        kt0 = slice * per;
-        nk = min(per, nk_all - kt0);
-        if (nk <= 0) return;                 // (uniform per workgroup)
+    const int ntiles = p.tiles_m * p.tiles_n;
+    if constexpr (A_KM) {
+        if (p.mix_na >= 0) {
+            // mixed split-K: 1-D grid; blocks [0, na * sa) = tiles [0, na) x sa slices (tile fastest), then the other tiles x (sa + 1)
+            const int na = p.mix_na, sa = p.mix_sa;
+            int bid = blockIdx.x, tile, slice, per;
+            if (bid < na * sa) { tile = bid % na; slice = bid / na; per = (nk_all + sa - 1) / sa; }
+            else { bid -= na * sa; const int nb = ntiles - na; tile = na + bid % nb; slice = bid / nb; per = (nk_all + sa) / (sa + 1); }
+            const int kt0 = slice * per, nk = min(per, nk_all - kt0);
+            if (nk <= 0) return;                 // (uniform per workgroup)
+            gemm3_tiles<A_KM, B_KM, C_F32, GLU, true, false>(p, tile, 0, tile + 1, ntiles, kt0, nk);
+        } else {
+            const int kt0 = blockIdx.y * p.ktiles_per_split;
+            gemm3_tiles<A_KM, B_KM, C_F32, GLU, true, false>(p, blockIdx.x, 0, blockIdx.x + 1, ntiles, kt0,
+                                                             min(p.ktiles_per_split, nk_all - kt0));
+        }
     } else {
-        gemm_tile_coords(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        kt0 = blockIdx.y * p.ktiles_per_split;
-        nk = min(p.ktiles_per_split, nk_all - kt0);
+        // whole-K tiles: gridDim.x <= tiles workgroups (one per CU) walk tiles b, b + grid, ...; a multiple-of-8 grid keeps a
+        // workgroup's tiles on the XCD-contiguous run of the raster its XCD owns
+        gemm3_tiles<A_KM, B_KM, C_F32, GLU, true, true>(p, blockIdx.x, gridDim.x, ntiles, ntiles, 0, nk_all);
     }
-    gemm3_tile<A_KM, B_KM, C_F32, GLU>(p, tm, tn, kt0, nk);
 }
 
 // ================================================================================================ grouped weight gradients
@@ -901,10 +1073,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_group_kernel(GroupParams g
     p.accumulate = gp.overwrite ? 0 : 1;
     p.atomic = whole ? 0 : 1;
     const int ntiles = q.tiles_m * q.tiles_n, nk_all = (q.K + BK2 - 1) / BK2;
-    int tm, tn;
     // raster: the whole tiles and the sliced tiles are each a contiguous run of the problem's grouped tile order
-    gemm_tile_coords_plain(tile, q.tiles_m, q.tiles_n, q.group_m, tm, tn);
-    (void)ntiles;
+    p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.group_m = q.group_m;
     int kt0 = 0, nk = nk_all;
     if (!whole) {
         const int per = (nk_all + q.splits - 1) / q.splits;
@@ -912,18 +1082,36 @@ __global__ __launch_bounds__(512, 2) void gemm3_wgrad_group_kernel(GroupParams g
         nk = min(per, nk_all - kt0);
         if (nk <= 0) return;
     }
-    gemm3_tile<true, true, true, 0>(p, tm, tn, kt0, nk);
+    gemm3_tiles<true, true, true, 0, false, false>(p, tile, 0, tile + 1, ntiles, kt0, nk);
 }
 
 template <bool A_KM, bool B_KM, bool C_F32, int GLU = 0>
 int launch3(const GemmParams& p, hipStream_t st) {
-    constexpr int lds = 2 * (256 + 256) * 128;
+    constexpr int lds = GEMM3_LDS;
     static std::atomic<uint64_t> lds_ok{0};
     kalle_allow_lds(reinterpret_cast<const void*>(gemm3_kernel<A_KM, B_KM, C_F32, GLU>), lds, lds_ok);
     dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
     if (p.mix_na >= 0) {
         const int ntiles = p.tiles_m * p.tiles_n;
         grid = dim3(p.mix_na * p.mix_sa + (ntiles - p.mix_na) * (p.mix_sa + 1), 1);
+    } else if (!A_KM) {
+        // persistent: one workgroup per CU (160 KiB of LDS each) walks its tiles; KALLE_GEMM_PERSIST=0: one workgroup per tile
+        // (the same code with a grid of `tiles` workgroups: every workgroup finds no next tile)
+        if (p.splits != 1) return KALLE_ERR_UNSUPPORTED;
+        static const bool persist = !(getenv("KALLE_GEMM_PERSIST") && atoi(getenv("KALLE_GEMM_PERSIST")) == 0);
+        const int cus = kalle_cu_count();
+        if (persist && (int)grid.x > cus) {
+            // experiment switch: "us" for every shape, or "glu2:us" for the fused SwiGLU backward only
+            static const char* de = getenv("KALLE_GEMM_DEPHASE_US");
+            GemmParams q = p;
+            if (de && (int)grid.x >= 4 * cus) {
+                const bool only_glu2 = !strncmp(de, "glu2:", 5);
+                if (!only_glu2 || GLU == 2) q.dephase_ticks = (int)(atof(only_glu2 ? de + 5 : de) * 100.0);
+            }
+            grid.x = cus;
+            KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32, GLU>), grid, block, lds, st, q);
+            return kalle_check_launch();
+        }
     }
     KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32, GLU>), grid, block, lds, st, p);
     return kalle_check_launch();
@@ -1320,6 +1508,9 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
     return kalle_check_launch();
 }
 
+static unsigned long long* g_stamps = nullptr;      // diagnostics only (kalle_gemm_debug_stamps)
+extern "C" int kalle_gemm_debug_stamps(void* buf) { g_stamps = static_cast<unsigned long long*>(buf); return KALLE_OK; }
+
 static thread_local int g_last_plan = 0;
 extern "C" int kalle_gemm_last_plan(void) { return g_last_plan; }
 
@@ -1356,6 +1547,7 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
             (p.residual && (!al16(p.residual) || (p.ldr & 3))))
             return KALLE_ERR_ARG;
     }
+    p.stamps = g_stamps;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool f32 = c_dtype == KALLE_F32;
     if (force_mode() != 1) {
@@ -1506,7 +1698,7 @@ extern "C" int kalle_gemm_wgrad_group(const kalle_wgrad_problem* problems, int n
         KALLE_LAUNCH(gemm3_group_zero_kernel, dim3(4 * (ntot - b1)), dim3(256), 0, static_cast<hipStream_t>(stream), gp);
         if (kalle_check_launch() != KALLE_OK) return KALLE_ERR_LAUNCH;
     }
-    constexpr int lds = 2 * (256 + 256) * 128;
+    constexpr int lds = GEMM3_LDS;
     static std::atomic<uint64_t> lds_ok{0};
     kalle_allow_lds(reinterpret_cast<const void*>(gemm3_wgrad_group_kernel), lds, lds_ok);
     KALLE_LAUNCH(gemm3_wgrad_group_kernel, dim3(b2), dim3(512), lds, static_cast<hipStream_t>(stream), gp);

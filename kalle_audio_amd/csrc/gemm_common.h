@@ -33,6 +33,12 @@ struct GemmParams {
     // few-rows split-K (gemm2 only): K slice s stores its partial tile to C + s * slab_stride (plain stores, summed in a fixed
     // order by the finishing pass: deterministic, and plain stores run ~4x the rate of float atomics); 0: off
     int64_t slab_stride;
+    // diagnostics (tools/gemm_stamps.py; NULL in every product call): [workgroup][2 waves][8] s_memrealtime stamps (100 MHz) of
+    // the 256 x 256 kernel's phases - entry, first tile landed, main loop done, epilogue barrier passed, stores issued, stores done
+    unsigned long long* stamps;
+    // persistent 256 x 256 kernel: every second group of 8 workgroups starts this many 10-ns ticks late, so that the CUs' epilogue
+    // bursts (HBM-bound when all 256 fall together) interleave with the other half's main loops (0: lockstep)
+    int dephase_ticks;
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a

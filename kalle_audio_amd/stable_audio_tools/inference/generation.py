@@ -4,14 +4,39 @@ sampler with batched CFG (221-234) -> pretransform.decode (244-247).
 
 Objectives: "rectified_flow" runs sample_rf -> sample_discrete_euler exactly as the reference (sampling.py:200-232);
 "v" is routed by the reference to third-party k-diffusion (`sample_k`, absent here) - this build runs the in-tree v-DDIM
-sampler instead (sampling.py:47-86, the call the reference keeps commented out at generation.py:236).  Inpainting /
-variations (init_audio, mask_args) are not carried over."""
+sampler instead (sampling.py:47-86, the call the reference keeps commented out at generation.py:236).
+
+init_audio / mask_args (generation.py:164-224): carried over for rectified flow exactly as the reference runs them -
+variations start from `init (1 - sigma_max) + noise sigma_max` with sigma_max = init_noise_level (sampling.py:200-232); with
+mask_args the reference cuts / pastes the init audio and builds the soft mask but its rectified-flow branch hands neither the
+mask nor a sigma_max to sample_rf, so the call degenerates to plain sampling (pinned by tests/golden/generate_init_audio.npz).
+For the "v" objective both live in k-diffusion and are refused."""
+import math
 import os
 
 import numpy as np
 import torch
 
-from .sampling import sample, sample_discrete_euler
+from .sampling import sample, sample_discrete_euler, sample_rf
+from .utils import prepare_audio
+
+
+def build_mask(sample_size, mask_args):
+    """generation.py:254-274: soft mask (0 = fresh generation, 1 = keep the input) with Hann ramps"""
+    maskstart = math.floor(mask_args["maskstart"] / 100.0 * sample_size)
+    maskend = math.ceil(mask_args["maskend"] / 100.0 * sample_size)
+    softnessL = round(mask_args["softnessL"] / 100.0 * sample_size)
+    softnessR = round(mask_args["softnessR"] / 100.0 * sample_size)
+    marination = mask_args["marination"]
+    hannL = torch.hann_window(softnessL * 2, periodic=False)[:softnessL]
+    hannR = torch.hann_window(softnessR * 2, periodic=False)[softnessR:]
+    mask = torch.zeros((sample_size))
+    mask[maskstart:maskend] = 1
+    mask[maskstart:maskstart + softnessL] = hannL
+    mask[maskend - softnessR:maskend] = hannR
+    if marination > 0:
+        mask = mask * (1 - marination)
+    return mask
 
 
 def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: dict = None, conditioning_tensors=None,
@@ -19,8 +44,10 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
                             sample_size: int = 2097152, sample_rate: int = 48000, seed: int = -1, device: str = "cuda",
                             init_audio=None, init_noise_level: float = 1.0, mask_args: dict = None, return_latents=False,
                             eta=0.0, **sampler_kwargs):
-    if init_audio is not None or mask_args is not None:
-        raise NotImplementedError("generate_diffusion_cond(init_audio / mask_args): inpainting and variations are not built")
+    if init_audio is not None and model.diffusion_objective != "rectified_flow":
+        raise NotImplementedError("generate_diffusion_cond(init_audio) for the v objective runs inside third-party k-diffusion "
+                                  "(sample_k) in the reference; only the rectified-flow branch is in its tree")
+    audio_sample_size = sample_size
     if model.pretransform is not None:
         sample_size = sample_size // model.pretransform.downsampling_ratio
     seed = seed if seed != -1 else np.random.randint(0, 2 ** 32 - 1, dtype=np.uint32)
@@ -40,8 +67,31 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
         neg = model.get_conditioning_inputs(negative_conditioning_tensors, negative=True)
     else:
         neg = {}
-    for k in ("sigma_min", "sampler_type", "sigma_max", "rho"):      # k-diffusion knobs of the reference's call sites
-        sampler_kwargs.pop(k, None)
+    init_data = None
+    if init_audio is not None:                                       # generation.py:164-183
+        in_sr, init_audio = init_audio
+        io_channels = model.pretransform.io_channels if model.pretransform is not None else model.io_channels
+        init_data = prepare_audio(init_audio, in_sr=in_sr, target_sr=model.sample_rate, target_length=audio_sample_size,
+                                  target_channels=io_channels, device=model_device)
+        if model.pretransform is not None:
+            init_data = model.pretransform.encode(init_data)
+        init_data = init_data.repeat(batch_size, 1, 1)
+        if mask_args is not None:                                    # 186-214 (the mask is built and, as there, not used)
+            cropfrom = math.floor(mask_args["cropfrom"] / 100.0 * sample_size)
+            pastefrom = math.floor(mask_args["pastefrom"] / 100.0 * sample_size)
+            pasteto = math.ceil(mask_args["pasteto"] / 100.0 * sample_size)
+            assert pastefrom < pasteto, "Paste From should be less than Paste To"
+            croplen = pasteto - pastefrom
+            if cropfrom + croplen > sample_size:
+                croplen = sample_size - cropfrom
+            cutpaste = init_data.new_zeros(init_data.shape)
+            cutpaste[:, :, pastefrom:pastefrom + croplen] = init_data[:, :, cropfrom:cropfrom + croplen]
+            init_data = cutpaste
+            build_mask(sample_size, mask_args)
+        else:
+            sampler_kwargs["sigma_max"] = init_noise_level           # 215-218: variations
+    for k in ("sigma_min", "sampler_type", "rho") + (() if init_data is not None else ("sigma_max",)):
+        sampler_kwargs.pop(k, None)                                  # k-diffusion knobs of the reference's call sites
     # One sampler step is ~400 launches that take less GPU time than the host needs to issue them: the denoiser call is captured
     # into a HIP graph once per shape signature and replayed (kalle_audio_amd/graph.py; bit-identical to the eager launches;
     # KALLE_SAMPLE_GRAPH=0 keeps the eager path).  Only frozen models: a captured graph does not see parameter updates' new
@@ -64,8 +114,12 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
         sampled = sample(denoiser, noise, steps, eta, **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True,
                          rescale_cfg=True, **sampler_kwargs)
     elif model.diffusion_objective == "rectified_flow":
-        sampled = sample_discrete_euler(denoiser, noise, steps, **cond_inputs, **neg, cfg_scale=cfg_scale,
-                                        batch_cfg=True, rescale_cfg=True, **sampler_kwargs)
+        if init_data is not None:
+            sampled = sample_rf(denoiser, noise, init_data=init_data.to(noise.dtype), steps=steps, **sampler_kwargs,
+                                **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True, rescale_cfg=True)
+        else:
+            sampled = sample_discrete_euler(denoiser, noise, steps, **cond_inputs, **neg, cfg_scale=cfg_scale,
+                                            batch_cfg=True, rescale_cfg=True, **sampler_kwargs)
     else:
         raise ValueError(f"unknown diffusion objective {model.diffusion_objective!r}")
     if model.pretransform is not None and not return_latents:

@@ -29,6 +29,19 @@ def sample_discrete_euler(model, x, steps, sigma_max=1, **extra_args):
 
 
 @torch.no_grad()
+def sample_rf(model_fn, noise, init_data=None, steps=100, sigma_max=1, device="cuda", callback=None, cond_fn=None,
+              **extra_args):
+    """sampling.py:200-232: discrete Euler for rectified-flow models; with init_data (a variation) the start point is the
+    interpolation of the init latents and the noise at sigma_max"""
+    if sigma_max > 1:
+        sigma_max = 1
+    if cond_fn is not None:
+        raise NotImplementedError("sample_rf(cond_fn): guidance functions wrap third-party k-diffusion utilities")
+    x = init_data * (1 - sigma_max) + noise * sigma_max if init_data is not None else noise
+    return sample_discrete_euler(model_fn, x, steps, sigma_max, **extra_args)
+
+
+@torch.no_grad()
 def sample(model, x, steps, eta, **extra_args):
     ts = x.new_ones([x.shape[0]])
     t = torch.linspace(1, 0, steps + 1)[:-1]

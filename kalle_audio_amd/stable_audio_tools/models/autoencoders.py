@@ -124,18 +124,57 @@ class WNConvTranspose1d(_WNBase):
                                          alpha=a, beta=b, logscale=ls, post_act=_post_act(post_act), want_raw=want_raw)
 
 
+class Activation1d(nn.Module):
+    """alias_free_torch.Activation1d(act) as autoencoders.py:34-35 wraps it around every activation when
+    `antialias_activation=True`: 2x kaiser-sinc up-sampling -> activation -> 2x low-pass down-sampling (12 taps each).  The
+    package is third-party and absent from the reference tree: restated from its published algorithm (oracle.activation1d),
+    PARITY UNPINNED - as for the mel-VAE's AMP blocks (kalle_audio_amd/flows.py), whose fused kernel this is.  It runs as its
+    own pass (one read + one write), so the convs around it see plain inputs; inference only."""
+
+    def __init__(self, activation):
+        super().__init__()
+        from ... import conv_ops
+        self.act = activation
+        self.upsample = nn.Module()                 # the package's state-dict names: upsample.filter, downsample.lowpass.filter
+        self.upsample.register_buffer("filter", conv_ops.kaiser_sinc_filter12("cpu").view(1, 1, -1))
+        self.downsample = nn.Module()
+        self.downsample.lowpass = nn.Module()
+        self.downsample.lowpass.register_buffer("filter", conv_ops.kaiser_sinc_filter12("cpu").view(1, 1, -1))
+
+    def forward(self, x):
+        from ... import conv_ops
+        x = _prep(x)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("antialias_activation has no backward kernel (the reference freezes the VAE in every script)")
+        f = self.upsample.filter.view(-1)
+        if isinstance(self.act, SnakeBeta):
+            return conv_ops.act1d(x, f, self.act.alpha.detach().float(), self.act.beta.detach().float(), self.act.alpha_logscale)
+        if isinstance(self.act, nn.ELU):
+            return conv_ops.act1d(x, f, None, None, True)
+        raise NotImplementedError(f"Activation1d({type(self.act).__name__})")
+
+
 def get_activation(activation: Literal["elu", "snake", "none"], antialias=False, channels=None) -> nn.Module:
     """autoencoders.py:24-37"""
-    if antialias:
-        raise NotImplementedError("antialias_activation wraps the third-party alias_free_torch.Activation1d "
-                                  "(not in the reference tree)")
     if activation == "elu":
-        return nn.ELU()
-    if activation == "snake":
-        return SnakeBeta(channels)
-    if activation == "none":
-        return nn.Identity()
-    raise ValueError(f"Unknown activation {activation}")
+        act = nn.ELU()
+    elif activation == "snake":
+        act = SnakeBeta(channels)
+    elif activation == "none":
+        act = nn.Identity()
+    else:
+        raise ValueError(f"Unknown activation {activation}")
+    if antialias:
+        act = Activation1d(act)
+    return act
+
+
+def _ac(conv, x, act, **kw):
+    """conv(act(x)): an anti-aliased activation cannot ride in a conv's input staging - it runs first, as its own pass, and the
+    conv sees a plain input; a plain activation is fused into the staging as usual"""
+    if isinstance(act, Activation1d):
+        return conv(act(x), **kw)
+    return conv(x, act=act, **kw)
 
 
 class ResidualUnit(nn.Module):
@@ -147,6 +186,7 @@ class ResidualUnit(nn.Module):
     def __init__(self, in_channels, out_channels, dilation, use_snake=False, antialias_activation=False):
         super().__init__()
         self.dilation = dilation
+        self.antialias = antialias_activation
         padding = (dilation * (7 - 1)) // 2
         self.layers = nn.Sequential(
             get_activation("snake" if use_snake else "elu", antialias=antialias_activation, channels=out_channels),
@@ -159,6 +199,9 @@ class ResidualUnit(nn.Module):
         """x_act: layers[0](x) if the producer already stored it (then the k=7 conv stages its input without any activation
         work); dual: return (post_act(y), y) - the pair the next unit wants"""
         x = _prep(x)
+        if self.antialias:              # plain composition (the producer-side activation fusion needs pointwise activations)
+            assert post_act is None and x_act is None and not dual
+            return _ac(self.layers[3], _ac(self.layers[1], x, self.layers[0]), self.layers[2], residual=x)
         if _wants_grad(self, x):        # training: two autograd units, raw tensors in between
             h = self.layers[1](x, act=self.layers[0])
             return self.layers[3](h, act=self.layers[2], residual=x)
@@ -174,6 +217,7 @@ class EncoderBlock(nn.Module):
 
     def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False):
         super().__init__()
+        self.antialias = antialias_activation       # (the reference hands it to the block's own activation only, not to the units)
         self.layers = nn.Sequential(
             ResidualUnit(in_channels=in_channels, out_channels=in_channels, dilation=1, use_snake=use_snake),
             ResidualUnit(in_channels=in_channels, out_channels=in_channels, dilation=3, use_snake=use_snake),
@@ -185,6 +229,9 @@ class EncoderBlock(nn.Module):
     def forward(self, x, post_act=None, x_act=None, dual=False):
         """x_act = layers[0].layers[0](x) if the producer stored it; dual: the strided conv returns (post_act(y), y)"""
         ru = self.layers
+        if self.antialias:
+            assert post_act is None and x_act is None and not dual
+            return _ac(ru[4], ru[2](ru[1](ru[0](x))), ru[3])
         if _wants_grad(self, x):
             return ru[4](ru[2](ru[1](ru[0](x))), act=ru[3])
         xa, x = ru[0](x, post_act=ru[1].layers[0], x_act=x_act, dual=True)
@@ -199,6 +246,7 @@ class DecoderBlock(nn.Module):
     def __init__(self, in_channels, out_channels, stride, use_snake=False, antialias_activation=False,
                  use_nearest_upsample=False):
         super().__init__()
+        self.antialias = antialias_activation
         self.nearest = stride if use_nearest_upsample else 0
         if use_nearest_upsample:        # autoencoders.py:87-96; same Sequential nesting, so the state-dict keys match
             upsample_layer = nn.Sequential(
@@ -221,6 +269,13 @@ class DecoderBlock(nn.Module):
         # both, so no k=7 conv spends VALU time re-activating its input tile once per output-channel tile
         ru = self.layers
         up = ru[1]
+        if self.antialias:              # act -> up-sample -> units, one pass each (low-pass filtering does not commute with repetition)
+            assert not pre_activated and post_act is None
+            x = ru[0](x)
+            if self.nearest:
+                from ... import conv_train
+                x, up = conv_train.UpsampleNearestFn.apply(_prep(x).float(), self.nearest), ru[1][1]
+            return ru[4](ru[3](ru[2](up(x))))
         if self.nearest:
             # a pointwise activation commutes with sample repetition: repeat x, then the conv activates while it stages
             from ... import conv_train
@@ -242,6 +297,7 @@ class OobleckEncoder(nn.Module):
         super().__init__()
         c_mults = [1] + c_mults
         self.depth = len(c_mults)
+        self.antialias = antialias_activation       # (autoencoders.py:136-137 does not hand it to the encoder blocks)
         layers = [WNConv1d(in_channels=in_channels, out_channels=c_mults[0] * channels, kernel_size=7, padding=3)]
         for i in range(self.depth - 1):
             layers += [EncoderBlock(in_channels=c_mults[i] * channels, out_channels=c_mults[i + 1] * channels,
@@ -254,7 +310,12 @@ class OobleckEncoder(nn.Module):
     def forward(self, x):
         n = len(self.layers)
         if n == 3:
-            return self.layers[2](self.layers[0](x), act=self.layers[1])
+            return _ac(self.layers[2], self.layers[0](x), self.layers[1])
+        if self.antialias:
+            x = self.layers[0](x)
+            for i in range(1, n - 2):
+                x = self.layers[i](x)
+            return _ac(self.layers[n - 1], x, self.layers[n - 2])
         if _wants_grad(self, x):
             x = self.layers[0](x)
             for i in range(1, n - 2):
@@ -278,6 +339,7 @@ class OobleckDecoder(nn.Module):
         super().__init__()
         c_mults = [1] + c_mults
         self.depth = len(c_mults)
+        self.antialias = antialias_activation
         layers = [WNConv1d(in_channels=latent_dim, out_channels=c_mults[-1] * channels, kernel_size=7, padding=3)]
         for i in range(self.depth - 1, 0, -1):
             layers += [DecoderBlock(in_channels=c_mults[i] * channels, out_channels=c_mults[i - 1] * channels,
@@ -293,6 +355,11 @@ class OobleckDecoder(nn.Module):
 
     def forward(self, x):
         n = len(self.layers)
+        if self.antialias:
+            x = self.layers[0](x)
+            for i in range(1, n - 3):
+                x = self.layers[i](x)
+            return _ac(self.layers[n - 2], x, self.layers[n - 3], post=1 if isinstance(self.layers[n - 1], nn.Tanh) else 0)
         if _wants_grad(self, x):
             x = self.layers[0](x)
             for i in range(1, n - 3):

@@ -831,6 +831,68 @@ def generate(sd_dit, cfg, sd_vae, vae_strides, noise, cond_inputs, steps, cfg_sc
     return pretransform_decode(sd_vae, lat, vae_strides, True, scale, True)
 
 
+def prepare_audio(audio, target_length, target_channels):
+    """inference/utils.py:20-40 for in_sr == target_sr (the resampler is third-party torchaudio): PadCrop(randomize=False)
+    (data/utils.py:8-20: crop or zero-pad on the right), batch dimension, mono <-> stereo (utils.py:5-18)"""
+    n, s_ = audio.shape
+    out = audio.new_zeros([n, target_length])
+    out[:, :min(s_, target_length)] = audio[:, :target_length]
+    out = out.unsqueeze(0)
+    if target_channels == 1:
+        out = out.mean(1, keepdim=True)
+    elif target_channels == 2:
+        if out.shape[1] == 1:
+            out = out.repeat(1, 2, 1)
+        elif out.shape[1] > 2:
+            out = out[:, :2, :]
+    return out
+
+
+def build_mask(sample_size, mask_args):
+    """inference/generation.py:254-274: soft inpainting mask with Hann ramps (1 = keep the input)"""
+    maskstart = math.floor(mask_args["maskstart"] / 100.0 * sample_size)
+    maskend = math.ceil(mask_args["maskend"] / 100.0 * sample_size)
+    sl = round(mask_args["softnessL"] / 100.0 * sample_size)
+    sr = round(mask_args["softnessR"] / 100.0 * sample_size)
+    hl = torch.hann_window(sl * 2, periodic=False)[:sl]
+    hr = torch.hann_window(sr * 2, periodic=False)[sr:]
+    mask = torch.zeros((sample_size))
+    mask[maskstart:maskend] = 1
+    mask[maskstart:maskstart + sl] = hl
+    mask[maskend - sr:maskend] = hr
+    if mask_args["marination"] > 0:
+        mask = mask * (1 - mask_args["marination"])
+    return mask
+
+
+def generate_variation(sd_dit, cfg, sd_vae, vae_strides, noise, init_audio, cond_inputs, steps, cfg_scale, init_noise_level,
+                       scale=1.0, mask_args=None, return_latents=False, audio_channels=2):
+    """generate_diffusion_cond(init_audio=...) for rectified flow (generation.py:164-228 -> sampling.py:200-232): prepare the init
+    audio, encode it if the model is latent, x = init (1 - sigma_max) + noise sigma_max with sigma_max = init_noise_level, Euler
+    from sigma_max.  With mask_args the reference cuts / pastes and builds the mask (186-214) but passes neither the mask nor a
+    sigma_max on: sigma_max stays 1 and the init data drops out of x."""
+    B, _, T_ = noise.shape
+    if sd_vae is not None:
+        ratio = 1
+        for s_ in vae_strides:
+            ratio *= s_
+        init = prepare_audio(init_audio, T_ * ratio, audio_channels)
+        init = pretransform_encode(sd_vae, init, vae_strides, True, scale)
+    else:
+        init = prepare_audio(init_audio, T_, noise.shape[1])
+    init = init.repeat(B, 1, 1)
+    sigma_max = min(init_noise_level, 1.0)
+    if mask_args is not None:
+        build_mask(T_, mask_args)                    # (built and dropped, as the reference's rectified-flow branch does)
+        sigma_max = 1.0
+    x = init * (1 - sigma_max) + noise * sigma_max
+    fn = lambda x_, t_: dit_forward(sd_dit, cfg, x_, t_, cfg_scale=cfg_scale, **cond_inputs)
+    lat = sample_euler(fn, x, steps, sigma_max)
+    if return_latents or sd_vae is None:
+        return lat
+    return pretransform_decode(sd_vae, lat, vae_strides, True, scale, True)
+
+
 def export_int16(audio):
     """infer_0723.py:292-293: "b d n -> d (b n)", divide by the peak, clamp, * 32767, int16"""
     o = audio.permute(1, 0, 2).reshape(audio.shape[1], -1).float()

@@ -243,3 +243,31 @@ def test_ema_schedule():
     assert big.next() == 0.9999
     sk = EMASchedule(update_every=10, update_after_step=0)
     assert [sk.next() is None for _ in range(11)] == [False] + [True] * 9 + [False]
+
+
+def test_shim_pythonpath_needs_no_edited_line(tmp_path):
+    """`PYTHONPATH=<repo>/shim python script.py` - the script's own directory holds modules called `model`,
+    `model_sigmaVAE`, `flows` and a package `stable_audio_tools` (as the reference's root does) that must NOT be the ones
+    imported; the script itself has no kalle-specific line"""
+    import subprocess
+    root = ROOT
+    for name in ("model.py", "model_sigmaVAE.py", "flows.py"):
+        (tmp_path / name).write_text("raise RuntimeError('the reference module was imported')\n")
+    (tmp_path / "stable_audio_tools").mkdir()
+    (tmp_path / "stable_audio_tools" / "__init__.py").write_text("raise RuntimeError('the reference package was imported')\n")
+    (tmp_path / "train.py").write_text(
+        "from model import Llasa as A\n"
+        "from model_sigmaVAE import Llasa as B\n"
+        "from stable_audio_tools import create_model_from_config\n"
+        "from stable_audio_tools.models.utils import load_ckpt_state_dict\n"
+        "from stable_audio_tools.inference.generation import generate_diffusion_cond\n"
+        "from flows import BigVGANFlowVAE\n"
+        "print(A.__module__, B.__module__, create_model_from_config.__module__, BigVGANFlowVAE.__module__)\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "shim"))
+    r = subprocess.run([sys.executable, "train.py"], cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["kalle_audio_amd.model", "kalle_audio_amd.model_sigmaVAE",
+                                "kalle_audio_amd.stable_audio_tools.models.factory", "kalle_audio_amd.flows"], r.stdout
+    r = subprocess.run([sys.executable, "train.py"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(env, KALLE_SHIM="0"))
+    assert r.returncode != 0 and "the reference module was imported" in r.stderr      # switched off: the directory wins again

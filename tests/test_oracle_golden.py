@@ -435,6 +435,48 @@ def test_generate_end_to_end():
         close(ko.generate(sd_dit, cfg, sd_vae, [2, 4, 5], noise, ci, e["steps"], e["cfg_scale"], "v", 0.8), f["v/audio"], 5e-5)
 
 
+def init_audio_states(with_vae, seed):
+    e = gu.E2E
+    shapes = ko.dit_shapes(4, e["D"], 2, cond_token_dim=e["DC"], global_cond_dim=e["G"], project_cond_tokens=False)
+    st = gu.make_state([("model." + k, v) for k, v in shapes], seed)
+    sd_dit = {k[len("model."):]: T(v) for k, v in st.items()}
+    if not with_vae:
+        return sd_dit, None
+    vshapes = (ko.oobleck_encoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], True, "encoder.") +       # encoder latent_dim 4: see
+               ko.oobleck_decoder_shapes(2, 8, 4, [1, 2, 4], [2, 4, 5], True, "decoder."))         # make_golden_r03.py
+    return sd_dit, state(vshapes, 24, False)
+
+
+def test_generate_from_init_audio():
+    """generate_diffusion_cond(init_audio=..., init_noise_level=...[, mask_args=...]) run by the reference (round 3 fixture):
+    variation from 4-channel init data without a pretransform, the same with a VAE (mono init audio, cropped), and the
+    mask_args call - which the reference's rectified-flow branch turns into plain sampling"""
+    f = fx("generate_init_audio")
+    e = gu.E2E
+    cfg = dict(embed_dim=e["D"], depth=2, num_heads=2, global_cond_type="prepend")
+    ctx, cm, gl = e2e_cond(64)
+    ci = ko.conditioning_inputs({"prompt": (ctx, cm), "g": (gl, None)}, ["prompt"], ["g"])
+    torch.manual_seed(e["seed"])
+    noise = torch.randn([e["B"], 4, e["T"]])
+    margs = dict(cropfrom=10.0, pastefrom=20.0, pasteto=70.0, maskstart=20.0, maskend=70.0, softnessL=5.0, softnessR=8.0,
+                 marination=0.1)
+    with torch.no_grad():
+        sd_dit, _ = init_audio_states(False, 64)
+        init = T(gu.make_input("init_lat", (4, 100), 64))
+        close(ko.generate_variation(sd_dit, cfg, None, None, noise, init, ci, e["steps"], e["cfg_scale"], 0.6), f["lat/variation"], 2e-5)
+        close(ko.generate_variation(sd_dit, cfg, None, None, noise, init, ci, e["steps"], e["cfg_scale"], 0.6, mask_args=margs),
+              f["lat/masked"], 2e-5)
+        assert np.array_equal(f["lat/masked"], f["lat/plain"])         # (what the reference does with mask_args under rectified flow)
+        sd_dit, sd_vae = init_audio_states(True, 65)
+        wav = T(gu.make_input("init_wav", (1, 40 * e["T"] + 333), 65)) * 0.3
+        close(ko.generate_variation(sd_dit, cfg, sd_vae, [2, 4, 5], noise, wav, ci, e["steps"], e["cfg_scale"], 0.45, 0.8,
+                                    return_latents=True), f["vae/variation_latents"], 2e-5)
+        close(ko.generate_variation(sd_dit, cfg, sd_vae, [2, 4, 5], noise, wav, ci, e["steps"], e["cfg_scale"], 0.45, 0.8),
+              f["vae/variation_audio"], 5e-5)
+    m = ko.build_mask(125, margs)
+    assert m.shape == (125,) and float(m.max()) <= 0.9 + 1e-6 and float(m[:25].max()) == 0.0
+
+
 @pytest.mark.parametrize("tag,objective,pre,seed", [("v_uniform", "v", False, 62), ("rf_logit", "rectified_flow", False, 63),
                                                     ("v_pre", "v", True, 64)])
 def test_training_step_wrapper(tag, objective, pre, seed):

@@ -264,3 +264,104 @@ def test_chunked_encode_with_enable_grad_is_differentiable(dev):
     got.square().mean().backward()
     gn = [p.grad.norm().item() for p in ae.encoder.parameters() if p.grad is not None]
     assert gn and all(v == v for v in gn) and max(gn) > 0
+
+
+# ------------------------------------------------------------------------------------------------ boundary: variations / inpainting
+def test_generate_diffusion_cond_from_init_audio(dev):
+    """generate_diffusion_cond(init_audio=..., init_noise_level=...[, mask_args=...]) against the reference function (fixture
+    generate_init_audio.npz, tests/golden/make_golden_r03.py): variation without a pretransform, with a VAE (encode on the GPU),
+    and the mask_args call, which the reference's rectified-flow branch turns into plain sampling"""
+    import numpy as np
+    import golden_util as gu
+    from test_modules_gpu import T, fx, load_seeded
+    from test_round2_gpu import TensorConditioner, _e2e_cond
+    from stable_audio_tools.inference.generation import build_mask, generate_diffusion_cond
+    from stable_audio_tools.models import diffusion as KD
+    from stable_audio_tools.models.factory import create_model_from_config
+    from stable_audio_tools.models.pretransforms import AutoencoderPretransform
+    f = fx("generate_init_audio")
+    e = gu.E2E
+    ctx, cm, gl = _e2e_cond(64, dev)
+    cond = {"prompt": (ctx, cm), "g": (gl, None)}
+
+    def model(with_vae, seed):
+        dit = KD.DiTWrapper(io_channels=4, embed_dim=e["D"], depth=2, num_heads=2, cond_token_dim=e["DC"],
+                            project_cond_tokens=False, global_cond_dim=e["G"], transformer_type="continuous_transformer",
+                            global_cond_type="prepend")
+        load_seeded(dit, seed, dev)
+        pt = None
+        if with_vae:
+            cfg = gu.oobleck_cfg(True)
+            cfg["model"]["encoder"]["config"]["latent_dim"] = 4          # (see make_golden_r03.py)
+            pt = AutoencoderPretransform(load_seeded(create_model_from_config(cfg), 24, dev), scale=0.8)
+        return KD.ConditionedDiffusionModelWrapper(dit, TensorConditioner(), io_channels=4, sample_rate=16000,
+                                                   min_input_length=40, diffusion_objective="rectified_flow", pretransform=pt,
+                                                   cross_attn_cond_ids=["prompt"], global_cond_ids=["g"]).to(dev)
+
+    kw = dict(steps=e["steps"], cfg_scale=e["cfg_scale"], conditioning_tensors=cond, batch_size=e["B"], seed=e["seed"], device="cpu")
+    margs = dict(cropfrom=10.0, pastefrom=20.0, pasteto=70.0, maskstart=20.0, maskend=70.0, softnessL=5.0, softnessR=8.0,
+                 marination=0.1)
+    m = model(False, 64)
+    init = T(gu.make_input("init_lat", (4, 100), 64), dev)
+    var = generate_diffusion_cond(m, sample_size=e["T"], init_audio=(16000, init), init_noise_level=0.6, **kw)
+    assert cosine(var, f["lat/variation"]) > 0.999, cosine(var, f["lat/variation"])
+    plain = generate_diffusion_cond(m, sample_size=e["T"], **kw)
+    masked = generate_diffusion_cond(m, sample_size=e["T"], init_audio=(16000, init), init_noise_level=0.6, mask_args=margs, **kw)
+    assert cosine(masked, f["lat/masked"]) > 0.999 and torch.equal(masked, plain)
+    assert rel(var, plain) > 0.1                                         # the init data really entered the variation
+    m = model(True, 65)
+    wav = T(gu.make_input("init_wav", (1, 40 * e["T"] + 333), 65), dev) * 0.3
+    lat = generate_diffusion_cond(m, sample_size=40 * e["T"], init_audio=(16000, wav), init_noise_level=0.45, return_latents=True, **kw)
+    assert cosine(lat, f["vae/variation_latents"]) > 0.999, cosine(lat, f["vae/variation_latents"])
+    audio = generate_diffusion_cond(m, sample_size=40 * e["T"], init_audio=(16000, wav), init_noise_level=0.45, **kw)
+    assert cosine(audio, f["vae/variation_audio"]) > 0.999
+    with pytest.raises(NotImplementedError):                             # another sample rate needs torchaudio's resampler
+        generate_diffusion_cond(m, sample_size=40 * e["T"], init_audio=(22050, wav), **kw)
+    mk = build_mask(125, margs)
+    assert mk.shape == (125,) and abs(float(mk.max()) - 0.9) < 1e-6
+    m.diffusion_objective = "v"
+    with pytest.raises(NotImplementedError):
+        generate_diffusion_cond(m, sample_size=40 * e["T"], init_audio=(16000, wav), **kw)
+
+
+def test_antialias_activation_oobleck_units(dev):
+    """ResidualUnit / EncoderBlock / DecoderBlock(antialias_activation=True) (autoencoders.py:24-37): every activation wrapped in
+    alias_free_torch.Activation1d - third-party, absent from the reference tree, PARITY UNPINNED: checked against the oracle's
+    restatement of the package's published algorithm (oracle.activation1d), like the mel-VAE's AMP blocks"""
+    import golden_util as gu
+    from test_modules_gpu import T
+    from stable_audio_tools.models.autoencoders import DecoderBlock, EncoderBlock, ResidualUnit
+    torch.manual_seed(3)
+    for use_snake in (True, False):
+        ru = ResidualUnit(16, 16, dilation=3, use_snake=use_snake, antialias_activation=True).to(dev)
+        enc = EncoderBlock(16, 32, stride=4, use_snake=use_snake, antialias_activation=True).to(dev)
+        dec = DecoderBlock(32, 16, stride=4, use_snake=use_snake, antialias_activation=True).to(dev)
+        for mod in (ru, enc, dec):
+            for n, p in mod.named_parameters():
+                if n.endswith("alpha") or n.endswith("beta"):
+                    torch.nn.init.normal_(p, 0.0, 0.3)
+        x = torch.randn(2, 16, 200, device=dev)
+
+        def act_ref(a, t):
+            tc = t.detach().cpu()
+            if use_snake:
+                return ko.activation1d(tc, a.alpha.detach().cpu(), a.beta.detach().cpu(), logscale=True)
+            up = ko.upsample1d_2x(tc, ko.kaiser_sinc_filter1d(0.25, 0.3, 12))
+            return ko.downsample1d_2x(torch.nn.functional.elu(up), ko.kaiser_sinc_filter1d(0.25, 0.3, 12))
+
+        def conv_ref(c, t, transposed=False):
+            w = (c.weight_g * c.weight_v / c.weight_v.flatten(1).norm(dim=1).view(-1, 1, 1)).detach().cpu()
+            b = c.bias.detach().cpu() if c.bias is not None else None
+            if transposed:
+                return torch.nn.functional.conv_transpose1d(t, w, b, stride=c.stride, padding=c.padding)
+            return torch.nn.functional.conv1d(t, w, b, stride=c.stride, padding=c.padding, dilation=c.dilation)
+
+        with torch.no_grad():
+            y = ru(x)
+            L = ru.layers
+            want = x.cpu() + conv_ref(L[3], act_ref(L[2].act, conv_ref(L[1], act_ref(L[0].act, x))))
+            assert rel(y, want) < 1e-4, (use_snake, rel(y, want))
+            ye = enc(x)
+            assert ye.shape == (2, 32, 50) and torch.isfinite(ye).all()
+            yd = dec(ye)
+            assert yd.shape == (2, 16, 200) and torch.isfinite(yd).all()
