@@ -231,7 +231,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             const int gm = row0 + 16 * mt + (lane >> 3) + 8 * half;
             hv[half][0] = i32x4{0, 0, 0, 0};
             hv[half][1] = i32x4{0, 0, 0, 0};
-            if (gm < p.M && j0 < p.glu_inner) {
+            if (gm < p.M && j0 < p.glu_inner && !(p.dbg & 1)) {
                 const bf16_t* hp = static_cast<const bf16_t*>(p.glu_aux) + (int64_t)gm * 2 * p.glu_inner;
                 hv[half][0] = *reinterpret_cast<const i32x4*>(hp + j0);
                 hv[half][1] = *reinterpret_cast<const i32x4*>(hp + p.glu_inner + j0);
@@ -249,9 +249,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
         if constexpr (GLU == 2) load_h(d, hbuf[d]);
         if (pre_res) load_res(d, rbuf[d]);
     }
-    f32x2 sx2[4], sg2[4];           // GLU backward: bias-gradient partial sums of this lane's 8 columns (as pairs)
+    float sx[8], sg[8];             // GLU backward: bias-gradient partial sums of this lane's 8 columns
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sx2[e] = f32x2{0.f, 0.f}; sg2[e] = f32x2{0.f, 0.f}; }
+    for (int e = 0; e < 8; ++e) { sx[e] = 0.f; sg[e] = 0.f; }
     // the bias of a lane's columns is the same for every piece: loaded once (inside the loop each load sits behind the
     // previous piece's stores, which may alias it for all the compiler knows)
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, bias8[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -326,10 +326,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
             }
         } else if constexpr (GLU == 2) {
             // fused SwiGLU backward: acc = d(act)[m][j]; reads h, writes dh = (dact*silu(g), dact*x*silu'(g)), sums db.
-            // The stamps put this epilogue at 21 us per tile whatever the other CUs do (de-phased workgroups, deeper operand
-            // prefetch: no change) - a good half of it is this arithmetic, 16 elements per lane per piece.  It runs on PAIRS:
-            // f32x2 arithmetic lowers to v_pk_mul / v_pk_fma / v_pk_add_f32 (two elements per instruction; only v_exp / v_rcp stay
-            // scalar), with s = sigmoid(g), t = g s:  dx = d t,  dg = d x (s + t (1 - s)).
+            // (Round 3 tried the arithmetic on f32x2 pairs - v_pk_mul / v_pk_fma / v_pk_add_f32, one v_exp + v_rcp per element:
+            // 21.4 -> 23.1 us per tile, and no longer bit-identical to the unfused kernel.  The VALU work is not what this
+            // epilogue waits for; see the knock-out timings in DESIGN.md 5.3.)
             const int c8 = (lane & 7) * 8, j0 = col0 + c8;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -337,35 +336,31 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int gm = rbase + r;
                 if (gm < p.M && j0 < p.glu_inner) {
                     const i32x4 xv = hcur[half][0], gv = hcur[half][1];
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(patch + pidx(r, c8));
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(patch + pidx(r, c8 + 4));
-                    const float dv[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
                     i32x4 ox, og;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const f32x2 x = {bf16lo((uint32_t)xv[e]), bf16hi((uint32_t)xv[e])};
-                        const f32x2 gg = {bf16lo((uint32_t)gv[e]), bf16hi((uint32_t)gv[e])};
+                        const float x[2] = {bf16lo((uint32_t)xv[e]), bf16hi((uint32_t)xv[e])};
+                        const float gg[2] = {bf16lo((uint32_t)gv[e]), bf16hi((uint32_t)gv[e])};
                         // the unfused path rounds dact to bf16 between the GEMM and the activation backward
-                        const uint32_t dr = pack_bf16x2(dv[2 * e] * p.alpha, dv[2 * e + 1] * p.alpha);
-                        const f32x2 d = {bf16lo(dr), bf16hi(dr)};
-                        const f32x2 ng = gg * f32x2{-1.4426950408889634f, -1.4426950408889634f};
-                        const f32x2 en = {__builtin_amdgcn_exp2f(ng[0]), __builtin_amdgcn_exp2f(ng[1])};
-                        const f32x2 den = en + f32x2{1.f, 1.f};
-                        const f32x2 sgm = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-                        const f32x2 t = gg * sgm;
-                        const f32x2 dx = d * t;
-                        const f32x2 w = __builtin_elementwise_fma(t, f32x2{1.f, 1.f} - sgm, sgm);
-                        const f32x2 dg = (d * x) * w;
+                        const float d[2] = {bf16_to_f32(f32_to_bf16(patch[pidx(r, c8 + 2 * e)] * p.alpha)),
+                                            bf16_to_f32(f32_to_bf16(patch[pidx(r, c8 + 2 * e + 1)] * p.alpha))};
+                        float dx[2], dg[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float sgm = sigmoidf_(gg[q]);
+                            dx[q] = d[q] * gg[q] * sgm;
+                            dg[q] = d[q] * x[q] * sgm * (1.f + gg[q] * (1.f - sgm));
+                        }
                         ox[e] = (int)pack_bf16x2(dx[0], dx[1]);
                         og[e] = (int)pack_bf16x2(dg[0], dg[1]);
-                        const f32x2 rx = {bf16lo((uint32_t)ox[e]), bf16hi((uint32_t)ox[e])};   // bias gradient = column sums of the
-                        const f32x2 rg = {bf16lo((uint32_t)og[e]), bf16hi((uint32_t)og[e])};   // STORED (bf16) dh, as the unfused kernel
-                        sx2[e] += rx;
-                        sg2[e] += rg;
+                        sx[2 * e] += bf16lo((uint32_t)ox[e]); sx[2 * e + 1] += bf16hi((uint32_t)ox[e]);
+                        sg[2 * e] += bf16lo((uint32_t)og[e]); sg[2 * e + 1] += bf16hi((uint32_t)og[e]);
                     }
-                    bf16_t* dp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
-                    *reinterpret_cast<i32x4*>(dp + j0) = ox;
-                    *reinterpret_cast<i32x4*>(dp + p.glu_inner + j0) = og;
+                    if (!(p.dbg & 2)) {
+                        bf16_t* dp = reinterpret_cast<bf16_t*>(p.C) + (int64_t)gm * p.ldc;
+                        *reinterpret_cast<i32x4*>(dp + j0) = ox;
+                        *reinterpret_cast<i32x4*>(dp + p.glu_inner + j0) = og;
+                    }
                 }
             }
         } else if (p.atomic) {
@@ -425,9 +420,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, f32x4 (&acc)[
     if constexpr (GLU == 2) {
         if (p.glu_dbias) {
             // lanes with equal (lane & 7) own the same 8 columns: fold the 8 row-lanes, then 16 atomics from lanes 0-7
-            float sx[8], sg[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sx[2 * e] = sx2[e][0]; sx[2 * e + 1] = sx2[e][1]; sg[2 * e] = sg2[e][0]; sg[2 * e + 1] = sg2[e][1]; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -1548,6 +1540,8 @@ extern "C" int kalle_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const v
             return KALLE_ERR_ARG;
     }
     p.stamps = g_stamps;
+    static const int dbg_env = getenv("KALLE_GEMM_DBG") ? atoi(getenv("KALLE_GEMM_DBG")) : 0;   // knock-out timing (diagnostics)
+    p.dbg = dbg_env;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool f32 = c_dtype == KALLE_F32;
     if (force_mode() != 1) {

@@ -39,6 +39,7 @@ struct GemmParams {
     // persistent 256 x 256 kernel: every second group of 8 workgroups starts this many 10-ns ticks late, so that the CUs' epilogue
     // bursts (HBM-bound when all 256 fall together) interleave with the other half's main loops (0: lockstep)
     int dephase_ticks;
+    int dbg;        // knock-out timing of the fused SwiGLU backward epilogue (KALLE_GEMM_DBG): 1 = no h loads, 2 = no dh stores
 };
 
 // Workgroup id -> output tile.  (1) XCD-aware: blocks b, b+8, ... share an XCD (and its 4 MiB L2), so each XCD gets a
