@@ -193,12 +193,19 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     char* Qs = smem;
     char* Ks = smem + AT_TILE;
     char* Vs = smem + 2 * AT_TILE;
-    float* kbias = reinterpret_cast<float*>(smem + 3 * AT_TILE);  // [128]
+    float* kbias = reinterpret_cast<float*>(smem + 3 * AT_TILE);  // [128] + [32] for the folded tail
+    char* Kt = smem + 3 * AT_TILE + 640;                          // tail keys (fold_tail): two 16-row tiles of K and of V
+    char* Vt = Kt + 32 * AT_STRIDE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     // causal: the last query block streams the most key blocks - dispatch the heavy workgroups first
     const int b = blockIdx.z, h = blockIdx.y, q0 = (p.causal ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
+    // The DiT's cross-attention has 130 context tokens: the 2 keys beyond the first block used to cost a second pass through
+    // the staging code - barrier, global loads with nothing to hide their latency, barrier - 16 us of a 111-us call.  A tail of
+    // up to 32 keys (no rotary, no causal mask) is fetched WITH the first block into its own small tiles instead and multiplied
+    // right behind it: no further barrier, no exposed load.
+    const bool fold_tail = QT == 1 && !p.causal && p.rot == 0 && p.Nk > 128 && p.Nk <= 160;
     const int hk = h / (p.H / p.Hkv);
 
     const bf16_t* qsrc = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + h * 64;
@@ -211,9 +218,29 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         tile_load<NT>(tq, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.rot, tid);
         tile_load<NT>(tk, ksrc, p.ldk, 0, kv0, p.rot, tid);
         tile_load<NT>(tv, vsrc, p.ldv, 0, kv0, 0, tid);
+        i32x4 tt = i32x4{0, 0, 0, 0};                   // one 16-byte chunk of the tail per thread: K rows then V rows (zero beyond Nk)
+        if constexpr (QT == 1) {
+            if (fold_tail) {
+                const int row = (tid >> 3) & 31, key = 128 + row;
+                if (key < p.Nk)
+                    tt = *reinterpret_cast<const i32x4*>((tid < 256 ? ksrc + (int64_t)key * p.ldk : vsrc + (int64_t)key * p.ldv) +
+                                                         8 * (tid & 7));
+            }
+        }
         tile_store<NT>(Qs, tq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos);
         tile_store<NT>(Ks, tk, 0, kv0, p.cosT, p.sinT, p.rot, tid);
         tile_store<NT>(Vs, tv, 0, kv0, nullptr, nullptr, 0, tid);
+        if constexpr (QT == 1) {
+            if (fold_tail) {
+                *reinterpret_cast<i32x4*>((tid < 256 ? Kt : Vt) + ((tid >> 3) & 31) * AT_STRIDE + 16 * (tid & 7)) = tt;
+                if (tid < 32) {
+                    float bias = 0.f;
+                    if (128 + tid >= p.Nk) bias = -INFINITY;
+                    else if (p.mask && !p.mask[(int64_t)b * p.Nk + 128 + tid]) bias = NEG_BIG;
+                    kbias[128 + tid] = bias;
+                }
+            }
+        }
     }
     __syncthreads();
     bf16x8 qf[QT][2];
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
 
         // one key block: S^T tiles -> online softmax -> O^T += V^T P^T.  NKT = 16-key tiles processed: 8 for a full block, 2
         // for a short tail (the 2 keys S = 130 leaves behind would otherwise cost a whole block of MFMAs and exps)
-        auto block = [&](auto nkt_c) {
+        auto block = [&](auto nkt_c, const char* Kb, const char* Vb, const float* kbias) {
             constexpr int NKT = decltype(nkt_c)::value;
         f32x4 acc[NKT][QT];
             // S^T = K Q^T on top of the key bias (0 / masked / padding): the MFMA accumulates onto it, so masking costs no
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                 for (int qt = 0; qt < QT; ++qt) acc[kt][qt] = kb;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 kf = rowfrag(Ks, 16 * kt, s, lane);
+                    const bf16x8 kf = rowfrag(Kb, 16 * kt, s, lane);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][s], acc[kt][qt], 0, 0, 0);
@@ -319,15 +346,19 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                 for (int qt = 0; qt < QT; ++qt) pb[qt] = pack_pair(acc[2 * ks][qt], acc[2 * ks + 1][qt]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 vf = trfrag(Vs, 32 * ks, 32 * ks + 16, 16 * dt, lane);
+                    const bf16x8 vf = trfrag(Vb, 32 * ks, 32 * ks + 16, 16 * dt, lane);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[qt], o[dt][qt], 0, 0, 0);
                 }
             }
             };
-        if (kval > 32) block(std::integral_constant<int, 8>{});
-        else block(std::integral_constant<int, 2>{});
+        if (kval > 32) block(std::integral_constant<int, 8>{}, Ks, Vs, kbias);
+        else block(std::integral_constant<int, 2>{}, Ks, Vs, kbias);
+        if (fold_tail) {                                 // keys 128 .. Nk - 1 from their own tiles, staged with the first block
+            block(std::integral_constant<int, 2>{}, Kt, Vt, kbias + 128);
+            break;
+        }
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -1307,7 +1338,7 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
         else KALLE_LAUNCH(attn_decode_kernel<0>, grid, block, (size_t)Nk * 4, st, p);
         return kalle_check_launch();
     }
-    constexpr int lds = 3 * AT_TILE + 128 * 4;
+    constexpr int lds = 3 * AT_TILE + 160 * 4 + 2 * 32 * AT_STRIDE;     // Q | K | V tiles, key bias [128 + 32], folded tail tiles
     static std::atomic<uint64_t> lds_ok{0};
     kalle_allow_lds(reinterpret_cast<const void*>(attn_fwd_kernel<1>), lds, lds_ok);
     dim3 grid((Nq + 127) / 128, H, B), block(512);

@@ -365,3 +365,32 @@ def test_antialias_activation_oobleck_units(dev):
             assert ye.shape == (2, 32, 50) and torch.isfinite(ye).all()
             yd = dec(ye)
             assert yd.shape == (2, 16, 200) and torch.isfinite(yd).all()
+
+
+@pytest.mark.parametrize("Nq,Nk,grp,masked_tail", [(126, 130, 2, False), (126, 160, 2, True), (257, 150, 1, False), (15, 159, 4, True),
+                                                   (126, 161, 2, False)])
+def test_attention_forward_with_folded_tail_keys(dev, Nq, Nk, grp, masked_tail):
+    """the forward's folded tail (keys 128 .. Nk - 1 <= 159 staged with the first block, no second pass through the staging code;
+    161 keys take the ordinary second block): outputs AND the log-sum-exp the backward reads, against fp32 torch, with the tail
+    keys masked for one clip"""
+    from kalle_audio_amd import ops
+    from test_kernels_gpu import _attn_ref, _mk
+    B, Hkv = 2, 2
+    H = Hkv * grp
+    D, Dc = H * 64, Hkv * 64
+    q = (_mk((B, Nq, D), dev, seed=900 + Nk) * 0.8).bfloat16()
+    kv = (_mk((B, Nk, 2 * Dc), dev, seed=901 + Nk) * 0.8).bfloat16()
+    mask = torch.rand(B, Nk, device=dev) > 0.3
+    mask[:, 0] = True
+    if masked_tail:
+        mask[0, 128:] = False
+    k, v = kv.float().chunk(2, -1)
+    ref = _attn_ref(q.float(), k, v, mask, None, H, Hkv)
+    out, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H, Hkv=Hkv,
+                                 Nq=Nq, Nk=Nk, key_mask=mask)
+    assert rel(out, ref) < 1e-2, rel(out, ref)
+    qh = q.float().view(B, Nq, H, 64).transpose(1, 2)
+    kh = k.reshape(B, Nk, Hkv, 64).transpose(1, 2).repeat_interleave(grp, dim=1)
+    sc = (qh @ kh.transpose(-1, -2)) * 0.125
+    sc = sc.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
+    assert (lse - torch.logsumexp(sc, dim=-1)).abs().max().item() < 2e-2
