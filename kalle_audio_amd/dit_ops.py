@@ -263,6 +263,15 @@ class ContextKV:
         self.dkv = None
         self.left = self.L                                     # layers whose backward has not run yet
 
+    @classmethod
+    def preprojected(cls, kv, L):
+        """forward-only view of projections computed elsewhere (a sampling loop's constant conditioning)"""
+        o = cls.__new__(cls)
+        o.L, o.kv, o.ld = L, kv, kv.shape[1]
+        o.Dc = kv.shape[1] // (2 * L)
+        o.w_all, o.dkv, o.left = None, None, L
+        return o
+
     def grad_buffer(self):
         if self.dkv is None:
             self.dkv = torch.empty_like(self.kv)

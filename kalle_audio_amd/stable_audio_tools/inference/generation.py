@@ -110,6 +110,17 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale=6, conditioning: 
             g.weights_fingerprint = fp
             object.__setattr__(model, "_kalle_graphed", g)      # (not a submodule: keeps it out of state_dict / parameters)
         denoiser = g
+    # the conditioning is the same at every sampler step: project it ONCE (cond | uncond halves, to_cond_embed, to_global_embed,
+    # the cross-attention k | v of all layers) instead of once per step - same arithmetic, hoisted out of the loop
+    # (KALLE_SAMPLE_PRECOND=0 keeps it inside)
+    dit = getattr(model.model, "model", None)
+    if frozen and os.environ.get("KALLE_SAMPLE_PRECOND", "1") != "0" and hasattr(dit, "precompute_conditioning"):
+        pre = dit.precompute_conditioning(cross_attn_cond=cond_inputs.get("cross_attn_cond"),
+                                          negative_cross_attn_cond=neg.get("negative_cross_attn_cond"),
+                                          negative_cross_attn_mask=neg.get("negative_cross_attn_mask"),
+                                          global_embed=cond_inputs.get("global_cond"),
+                                          prepend_cond=cond_inputs.get("prepend_cond"), cfg_scale=cfg_scale)
+        sampler_kwargs.update(pre)
     if model.diffusion_objective == "v":
         sampled = sample(denoiser, noise, steps, eta, **cond_inputs, **neg, cfg_scale=cfg_scale, batch_cfg=True,
                          rescale_cfg=True, **sampler_kwargs)

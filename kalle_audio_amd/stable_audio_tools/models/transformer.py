@@ -284,7 +284,14 @@ class ContinuousTransformer(nn.Module):
             gated._kalle_bf16 = KF._to_bf16(ctx.detach().contiguous())
             gated._kalle_dctx = {}
             kwargs = dict(kwargs, context=gated)
-        self._project_context_for_all_layers(kwargs.get("context"))
+        pre_kv = kwargs.pop("kalle_ctx_kv", None)        # DiffusionTransformer.precompute_conditioning: k | v of all layers, done once
+        if pre_kv is not None and kwargs.get("context") is not None:
+            try:
+                kwargs["context"]._kalle_ckv = KF.D.ContextKV.preprojected(pre_kv, len(self.layers))
+            except (AttributeError, RuntimeError):
+                self._project_context_for_all_layers(kwargs.get("context"))
+        else:
+            self._project_context_for_all_layers(kwargs.get("context"))
         try:
             for layer in self.layers:
                 x = layer(x, rotary_pos_emb=rotary, global_cond=global_cond, mask=mask, **kwargs)

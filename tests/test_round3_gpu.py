@@ -394,3 +394,27 @@ def test_attention_forward_with_folded_tail_keys(dev, Nq, Nk, grp, masked_tail):
     sc = (qh @ kh.transpose(-1, -2)) * 0.125
     sc = sc.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
     assert (lse - torch.logsumexp(sc, dim=-1)).abs().max().item() < 2e-2
+
+
+def test_sampler_conditioning_hoisted_out_of_the_loop_is_bit_identical(dev, monkeypatch):
+    """generate_diffusion_cond projects the (constant) conditioning once per call - cond | uncond halves, to_cond_embed,
+    to_global_embed, the cross-attention k | v of all layers - instead of once per sampler step: same arithmetic, so the samples
+    must equal the in-loop path bit for bit, with and without negative conditioning, graph replay and eager"""
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    m = _small_dit(dev, seed=72)
+    m.eval().requires_grad_(False)
+    _, _, _, cond = _batch(dev, 2, 14)
+    neg = {"prompt": (cond["prompt"][0].flip(0), cond["prompt"][1]), "g": cond["g"]}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("KALLE_SAMPLE_GRAPH", graph)
+        for extra in ({}, {"negative_conditioning_tensors": neg}):
+            kw = dict(steps=5, cfg_scale=4.0, conditioning_tensors=cond, batch_size=2, sample_size=125, seed=11, device="cpu", **extra)
+            monkeypatch.setenv("KALLE_SAMPLE_PRECOND", "1")
+            a = generate_diffusion_cond(m, **kw).clone()
+            monkeypatch.setenv("KALLE_SAMPLE_PRECOND", "0")
+            b = generate_diffusion_cond(m, **kw).clone()
+            assert torch.equal(a, b), (graph, bool(extra), rel(a, b))
+    monkeypatch.setenv("KALLE_SAMPLE_PRECOND", "1")
+    c = generate_diffusion_cond(m, **dict(kw, cfg_scale=1.0))               # unguided: no batch doubling
+    monkeypatch.setenv("KALLE_SAMPLE_PRECOND", "0")
+    assert torch.equal(c, generate_diffusion_cond(m, **dict(kw, cfg_scale=1.0)))
