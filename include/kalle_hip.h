@@ -94,6 +94,10 @@ int kalle_gemm_last_plan(void);
  * K-tile landed, 2 main loop done, 3 epilogue barrier passed, 4 stores issued, 5 stores acknowledged (an extra wait that only
  * exists while the buffer is set).  NULL switches it off again.  Process-wide. */
 int kalle_gemm_debug_stamps(void* buf);
+/* the same for the attention kernels (tools/attn_stamps.py): [B * H workgroups][8] stamps of thread 0 - forward: 0 entry, 1 tiles
+ * staged, 2 computed, 3 stores issued, 4 stores acknowledged; fused self-attention backward: 0 entry, 1 tiles staged, 2 row
+ * statistics ready, 3 dK / dV computed, 4 dK / dV stored, 5 dQ computed, 6 stores issued, 7 acknowledged */
+int kalle_attn_debug_stamps(void* buf);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (bias-less gamma, eps 1e-5) with optional adaLN modulation - one wavefront per row.

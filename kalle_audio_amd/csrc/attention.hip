@@ -59,19 +59,41 @@ __device__ __forceinline__ void tile_load(TileRegs<NT>& t, const bf16_t* src, in
         t.v[1] = *reinterpret_cast<const i32x4*>(rp + 8 * cb);
     }
 }
+// The rotary factors of a thread's pair, fetched WITH the tile (rope_load next to tile_load) instead of inside tile_store: there
+// the table loads start only once the tile data has arrived - a second, dependent memory latency in front of the first barrier
+// (the round-3 stamps: 4.9 us of load + stage per self-attention workgroup against 2.8 us for the rotary-free cross-attention).
+struct RopeRegs { f32x4 c0, c1, s0, s1; };
+__device__ __forceinline__ RopeRegs rope_load(const float* __restrict__ cosT, const float* __restrict__ sinT, int row0,
+                                              int nvalid, int rot, int tid, int pos_off = 0) {
+    const int row = tid >> 2, j = tid & 3;
+    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, s0 = c0, s1 = c0;
+    if (row < nvalid && j < (rot >> 4)) {
+        const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+        const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+        c0 = *reinterpret_cast<const f32x4*>(cp); c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        s0 = *reinterpret_cast<const f32x4*>(sp); s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
+    return RopeRegs{c0, c1, s0, s1};
+}
+
 template <int NT>
 __device__ __forceinline__ void tile_store(char* lds, const TileRegs<NT>& t, int row0, int nvalid,
                                            const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
-                                           int tid, int pos_off = 0) {
+                                           int tid, int pos_off, bool use_pre, const RopeRegs pre) {
     const int row = tid >> 2, j = tid & 3;
     int ca, cb;
     tile_chunks(rot, j, ca, cb);
     i32x4 va = t.v[0], vb = t.v[1];
     if (row < nvalid && j < (rot >> 4)) {               // out_a = a cos - b sin, out_b = b cos + a sin (rotate_half)
-        const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
-        const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        f32x4 c0, c1, s0, s1;
+        if (use_pre) {
+            c0 = pre.c0; c1 = pre.c1; s0 = pre.s0; s1 = pre.s1;
+        } else {
+            const float* cp = cosT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+            const float* sp = sinT + (int64_t)(row0 + row + pos_off) * (rot >> 1) + j * 8;
+            c0 = *reinterpret_cast<const f32x4*>(cp); c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+            s0 = *reinterpret_cast<const f32x4*>(sp); s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = bf16lo((uint32_t)va[e]), a1 = bf16hi((uint32_t)va[e]);
@@ -84,6 +106,13 @@ __device__ __forceinline__ void tile_store(char* lds, const TileRegs<NT>& t, int
     }
     *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * ca) = va;
     *reinterpret_cast<i32x4*>(lds + row * AT_STRIDE + 16 * cb) = vb;
+}
+template <int NT>
+__device__ __forceinline__ void tile_store(char* lds, const TileRegs<NT>& t, int row0, int nvalid,
+                                           const float* __restrict__ cosT, const float* __restrict__ sinT, int rot,
+                                           int tid, int pos_off = 0) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    tile_store<NT>(lds, t, row0, nvalid, cosT, sinT, rot, tid, pos_off, false, RopeRegs{z, z, z, z});
 }
 template <int NT>
 __device__ __forceinline__ void stage_tile(char* lds, const bf16_t* src, int64_t ld, int row0, int nvalid,
@@ -181,7 +210,12 @@ struct AttnParams {
     // backward only
     const bf16_t* dout; float* delta;
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    unsigned long long* stamps;   // diagnostics (kalle_attn_debug_stamps): [workgroup][8] s_memrealtime stamps of wave 0, or NULL
 };
+__device__ __forceinline__ void attn_stamp(const AttnParams& p, int tid, int idx) {
+    if (p.stamps && tid == 0)
+        p.stamps[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * 8 + idx] = __builtin_amdgcn_s_memrealtime();
+}
 
 // ================================================================================================ forward
 // QT = 16-row query tiles per wave: 2 -> 4 waves per workgroup (wave = 32 queries), 1 -> 8 waves (wave = 16 queries,
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
     // up to 32 keys (no rotary, no causal mask) is fetched WITH the first block into its own small tiles instead and multiplied
     // right behind it: no further barrier, no exposed load.
     const bool fold_tail = QT == 1 && !p.causal && p.rot == 0 && p.Nk > 128 && p.Nk <= 160;
+    attn_stamp(p, tid, 0);
     const int hk = h / (p.H / p.Hkv);
 
     const bf16_t* qsrc = p.q + (int64_t)b * p.Nq * p.ldq + p.q_off + h * 64;
@@ -218,6 +253,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         tile_load<NT>(tq, qsrc, p.ldq, q0, min(128, p.Nq - q0), p.rot, tid);
         tile_load<NT>(tk, ksrc, p.ldk, 0, kv0, p.rot, tid);
         tile_load<NT>(tv, vsrc, p.ldv, 0, kv0, 0, tid);
+        const RopeRegs rq = rope_load(p.cosT, p.sinT, q0, min(128, p.Nq - q0), p.rot, tid, p.qpos);   // (rot == 0: no loads)
+        const RopeRegs rk = rope_load(p.cosT, p.sinT, 0, kv0, p.rot, tid);
         i32x4 tt = i32x4{0, 0, 0, 0};                   // one 16-byte chunk of the tail per thread: K rows then V rows (zero beyond Nk)
         if constexpr (QT == 1) {
             if (fold_tail) {
@@ -227,8 +264,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
                                                          8 * (tid & 7));
             }
         }
-        tile_store<NT>(Qs, tq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos);
-        tile_store<NT>(Ks, tk, 0, kv0, p.cosT, p.sinT, p.rot, tid);
+        tile_store<NT>(Qs, tq, q0, min(128, p.Nq - q0), p.cosT, p.sinT, p.rot, tid, p.qpos, p.rot != 0, rq);
+        tile_store<NT>(Ks, tk, 0, kv0, p.cosT, p.sinT, p.rot, tid, 0, p.rot != 0, rk);
         tile_store<NT>(Vs, tv, 0, kv0, nullptr, nullptr, 0, tid);
         if constexpr (QT == 1) {
             if (fold_tail) {
@@ -243,6 +280,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         }
     }
     __syncthreads();
+    attn_stamp(p, tid, 1);
     bf16x8 qf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -360,6 +398,7 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
             break;
         }
     }
+    attn_stamp(p, tid, 2);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const float lt = xor16_32_sum(l[qt]);
@@ -376,6 +415,11 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
             }
             if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + qi] = m[qt] * SM_SCALE + __logf(lt);
         }
+    }
+    if (p.stamps) {
+        attn_stamp(p, tid, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        attn_stamp(p, tid, 4);
     }
 }
 
@@ -696,7 +740,7 @@ __device__ __forceinline__ float& row_stat(char* tile, int row, int slot) {
     return *reinterpret_cast<float*>(tile + row * AT_STRIDE + 128 + 4 * slot);
 }
 
-__global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_fused_kernel(AttnParams p) {
     constexpr int NT = 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* RQ = smem;                  // pad slot 0: -lse * log2 e (-inf past the end), slot 1: -delta * scale
@@ -711,6 +755,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
     const bf16_t* kb = p.k + (int64_t)b * Nk * p.ldk + p.k_off + h * 64;
     const bf16_t* vb = p.v + (int64_t)b * Nk * p.ldv + p.v_off + h * 64;
     const bf16_t* dob = p.dout + (int64_t)b * N * p.ldo + h * 64;
+    attn_stamp(p, tid, 0);
 
     // ---- staging: all global loads in flight together, then rotary + LDS writes
     {
@@ -719,6 +764,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
         tile_load<NT>(td, dob, p.ldo, 0, N, 0, tid);
         tile_load<NT>(tk, kb, p.ldk, 0, Nk, p.rot, tid);
         tile_load<NT>(tv, vb, p.ldv, 0, Nk, 0, tid);
+        const RopeRegs rq = rope_load(p.cosT, p.sinT, 0, N, p.rot, tid, p.qpos);
+        const RopeRegs rk = rope_load(p.cosT, p.sinT, 0, Nk, p.rot, tid);
         // delta[q] = sum_d dO[q][d] O[q][d]: 4 threads per row, O straight from global (in flight with the tiles)
         const int drow = tid >> 2, dq4 = tid & 3;
         i32x4 o0v = i32x4{0, 0, 0, 0}, o1v = i32x4{0, 0, 0, 0};
@@ -727,11 +774,17 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
             o0v = *reinterpret_cast<const i32x4*>(op);
             o1v = *reinterpret_cast<const i32x4*>(op + 8);
         }
-        tile_store<NT>(RQ, tq, 0, N, p.cosT, p.sinT, p.rot, tid, p.qpos);
+        // the row statistics' inputs too (log-sum-exp of the query, mask byte of the key): requested now, used after the barrier
+        float lse_pre = 0.f;
+        bool key_ok = drow < Nk;
+        if (dq4 == 0 && drow < N) lse_pre = p.lse[((int64_t)b * p.H + h) * N + drow];
+        if (dq4 == 1 && key_ok && p.mask) key_ok = p.mask[(int64_t)b * Nk + drow] != 0;
+        tile_store<NT>(RQ, tq, 0, N, p.cosT, p.sinT, p.rot, tid, p.qpos, p.rot != 0, rq);
         tile_store<NT>(RD, td, 0, N, nullptr, nullptr, 0, tid);
-        tile_store<NT>(RK, tk, 0, Nk, p.cosT, p.sinT, p.rot, tid);
+        tile_store<NT>(RK, tk, 0, Nk, p.cosT, p.sinT, p.rot, tid, 0, p.rot != 0, rk);
         tile_store<NT>(RV, tv, 0, Nk, nullptr, nullptr, 0, tid);
         __syncthreads();
+        attn_stamp(p, tid, 1);
         const i32x4 d0v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4);
         const i32x4 d1v = *reinterpret_cast<const i32x4*>(RD + drow * AT_STRIDE + 32 * dq4 + 16);
         float dl = 0.f;
@@ -744,16 +797,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
         dl += __shfl_xor(dl, 2, 64);
         if (dq4 == 0) {
             const bool ok = drow < N;
-            row_stat(RQ, drow, 0) = ok ? -p.lse[((int64_t)b * p.H + h) * N + drow] * LOG2E : -INFINITY;
+            row_stat(RQ, drow, 0) = ok ? -lse_pre * LOG2E : -INFINITY;
             row_stat(RQ, drow, 1) = ok ? -dl * SM_SCALE : 0.f;
             if (ok) p.delta[((int64_t)b * p.H + h) * N + drow] = dl;      // (kept for callers that look at it)
         } else if (dq4 == 1) {
-            bool ok = drow < Nk;
-            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + drow] != 0;
-            row_stat(RK, drow, 0) = ok ? 0.f : -INFINITY;
+            row_stat(RK, drow, 0) = key_ok ? 0.f : -INFINITY;
         }
         __syncthreads();
     }
+    attn_stamp(p, tid, 2);
     const f32x2 c2 = f32x2{SM_SCALE_LOG2E, SM_SCALE_LOG2E}, sc2 = f32x2{SM_SCALE, SM_SCALE};
     const int orow = wave * 16;                  // this wave's 16 owner rows (keys in phase A, queries in phase B)
 
@@ -798,6 +850,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
                 g1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag(RD, 32 * pr, 32 * pr + 16, 16 * dt, lane), pb, g1[dt], 0, 0, 0);
             }
         }
+        attn_stamp(p, tid, 3);
         const int oi = orow + li;
         if (oi < Nk) {
             if (p.rot) {
@@ -833,6 +886,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
     }
 
     // =============================== phase B: queries own, keys stream -> dQ
+    attn_stamp(p, tid, 4);
     if (orow < N) {
         bf16x8 y1[2], y2[2];
 #pragma unroll
@@ -889,6 +943,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
                     }
                 }
             }
+            attn_stamp(p, tid, 5);
             bf16_t* dqp = p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -898,6 +953,11 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_kernel(AttnParams p) {
                 *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
             }
         }
+    }
+    if (p.stamps) {
+        attn_stamp(p, tid, 6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        attn_stamp(p, tid, 7);
     }
 }
 
@@ -952,6 +1012,12 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p
             tkv = *reinterpret_cast<const i32x4*>(kb + (int64_t)(128 + tj) * p.ldk + 8 * tc);
             tvv = *reinterpret_cast<const i32x4*>(vb + (int64_t)(128 + tj) * p.ldv + 8 * tc);
         }
+        // inputs of the per-row statistics, requested with the tiles (behind the barrier each was one more exposed latency)
+        float lse_pre = 0.f;
+        bool stat_ok = dq4 == 1 ? drow >= trow0 : drow < nmain;
+        if (dq4 == 0 && drow < N) lse_pre = p.lse[((int64_t)b * p.H + h) * N + drow];
+        if (dq4 == 1 && stat_ok && p.mask) stat_ok = p.mask[(int64_t)b * Nk + 128 + (drow - trow0)] != 0;
+        if (dq4 == 2 && with_kv && stat_ok && p.mask) stat_ok = p.mask[(int64_t)b * Nk + drow] != 0;
         tile_store<NT>(RQ, tq, 0, N, nullptr, nullptr, 0, tid);
         tile_store<NT>(RD, td, 0, N, nullptr, nullptr, 0, tid);
         if (with_kv) {
@@ -975,17 +1041,13 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p
         dl += __shfl_xor(dl, 2, 64);
         if (dq4 == 0) {
             const bool ok = drow < N;
-            row_stat(RQ, drow, 0) = ok ? -p.lse[((int64_t)b * p.H + h) * N + drow] * LOG2E : -INFINITY;
+            row_stat(RQ, drow, 0) = ok ? -lse_pre * LOG2E : -INFINITY;
             row_stat(RQ, drow, 1) = ok ? -dl * SM_SCALE : 0.f;
             if (ok && write_delta) p.delta[((int64_t)b * p.H + h) * N + drow] = dl;
         } else if (dq4 == 1) {
-            bool ok = drow >= trow0;                                   // this row holds tail key 128 + (drow - trow0)
-            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + 128 + (drow - trow0)] != 0;
-            row_stat(RQ, drow, 2) = ok ? 0.f : -INFINITY;
+            row_stat(RQ, drow, 2) = stat_ok ? 0.f : -INFINITY;          // this row holds tail key 128 + (drow - trow0)
         } else if (dq4 == 2 && with_kv) {
-            bool ok = drow < nmain;
-            if (ok && p.mask) ok = p.mask[(int64_t)b * Nk + drow] != 0;
-            row_stat(RK, drow, 0) = ok ? 0.f : -INFINITY;
+            row_stat(RK, drow, 0) = stat_ok ? 0.f : -INFINITY;
         }
         __syncthreads();
     };
@@ -1314,6 +1376,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
 
 }  // namespace
 
+static unsigned long long* g_attn_stamps = nullptr;      // diagnostics only
+extern "C" int kalle_attn_debug_stamps(void* buf) { g_attn_stamps = static_cast<unsigned long long*>(buf); return KALLE_OK; }
+
 extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const void* k, int64_t ldk, int k_off,
                                    const void* v, int64_t ldv, int v_off, void* out, int64_t ldo, float* lse,
                                    const float* rope_cos, const float* rope_sin, int rot, const uint8_t* key_mask,
@@ -1328,6 +1393,7 @@ extern "C" int kalle_attention_fwd(const void* q, int64_t ldq, int q_off, const 
     p.out = static_cast<bf16_t*>(out); p.ldo = ldo; p.lse = lse;
     p.cosT = rope_cos; p.sinT = rope_sin; p.rot = rot; p.mask = key_mask;
     p.B = B; p.H = H; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.causal = causal;
+    p.stamps = g_attn_stamps;
     if (causal && Nk < Nq) return KALLE_ERR_ARG;
     p.qpos = causal ? Nk - Nq : 0;
     if (Nq == 1 && Nk <= 15360) {   // decoding against a KV cache: scores of all keys fit in LDS (60 KB)
@@ -1367,6 +1433,7 @@ extern "C" int kalle_attention_bwd(const void* q, int64_t ldq, int q_off, const 
     p.qpos = causal ? Nk - Nq : 0;
     p.dout = static_cast<const bf16_t*>(dout); p.delta = delta;
     p.dq = static_cast<bf16_t*>(dq); p.dk = static_cast<bf16_t*>(dk); p.dv = static_cast<bf16_t*>(dv);
+    p.stamps = g_attn_stamps;
 
     // one block of queries and keys, one kv head per query head (the DiT's self-attention): everything in one kernel
     static const bool fused_env = !(getenv("KALLE_ATTN_FUSED_BWD") && atoi(getenv("KALLE_ATTN_FUSED_BWD")) == 0);
