@@ -36,9 +36,13 @@ def _needs(obj, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose=True, force=False):
+def build(verbose=True, force=False, extra_flags=(), out=None, objdir_name="build", only=None):
+    """extra_flags / out / objdir_name / only: a second library next to the product one for same-box A/B runs of build-time
+    switches (python -m kalle_audio_amd.build --variant NAME -DKALLE_...=...; run with KALLE_LIB_PATH=.../libkalle_hip_NAME.so)"""
+    global OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, objdir_name)
+    out = out or OUT
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "kalle_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -47,7 +51,7 @@ def build(verbose=True, force=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _needs(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -61,10 +65,15 @@ def build(verbose=True, force=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
-    if jobs or not os.path.exists(OUT):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-    return OUT
+    if jobs or not os.path.exists(out):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+        print(build(force=True, extra_flags=flags, out=os.path.join(HERE, f"libkalle_hip_{name}.so"), objdir_name="build_" + name))
+    else:
+        print(build(force="--force" in sys.argv))
