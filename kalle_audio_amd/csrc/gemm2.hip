@@ -883,19 +883,25 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
         ra.template read<0, 8>(so_cur, fa);
         rb.template read<0, 4>(so_cur, fb);
 
+        // (variant builds for knock-out timing of the main loop, tools/gemm_stamps.py: -DKALLE_GEMM_KNOCKOUT=1 no LDS-DMA after
+        // the prologue, =2 no fragment reads, =3 no MFMAs, =4 neither reads nor MFMAs; the product build has none of it)
+#ifndef KALLE_GEMM_KNOCKOUT
+#define KALLE_GEMM_KNOCKOUT 0
+#endif
+#define KO_READ(...) do { if (KALLE_GEMM_KNOCKOUT != 2 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
+#define KO_MFMA(...) do { if (KALLE_GEMM_KNOCKOUT != 3 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
         auto iteration = [&](auto issue_c, auto next_c) {
-            constexpr bool ISSUE = decltype(issue_c)::value, NEXT = decltype(next_c)::value;
+            constexpr bool ISSUE = decltype(issue_c)::value && KALLE_GEMM_KNOCKOUT != 1, NEXT = decltype(next_c)::value;
             // k-step 0 of this tile is in flight / landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            MFMA32(fa, fb);
+            KO_MFMA(MFMA32(fa, fb));
             __builtin_amdgcn_sched_barrier(0);
-            ra.template read<1, 8>(so_cur, fa);
-            rb.template read<1, 4>(so_cur, fb);
+            KO_READ(ra.template read<1, 8>(so_cur, fa); rb.template read<1, 4>(so_cur, fb));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my last reads of this stage are done
             __builtin_amdgcn_sched_barrier(0);
             if (!late) {
-                MFMA32(fa, fb);
+                KO_MFMA(MFMA32(fa, fb));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // hand-over: everybody's DMA of tile kt+1 has landed, everybody is done reading this stage
@@ -903,7 +909,7 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (late) {
-                MFMA32(fa, fb);
+                KO_MFMA(MFMA32(fa, fb));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (ISSUE) {      // this stage is free: start the DMA of tile kt+2 into it
@@ -912,8 +918,7 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
             }
             so_cur ^= STAGE;
             if constexpr (NEXT) {
-                ra.template read<0, 8>(so_cur, fa);
-                rb.template read<0, 4>(so_cur, fb);
+                KO_READ(ra.template read<0, 8>(so_cur, fa); rb.template read<0, 4>(so_cur, fb));
             }
             __builtin_amdgcn_sched_barrier(0);
         };
