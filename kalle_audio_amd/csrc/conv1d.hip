@@ -1046,7 +1046,14 @@ extern "C" int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packe
             } else if (tc.cow == 16) {
                 // 8 waves share one staged x tile for 128 output channels (pointwise convs: 32-channel chunks to cover
                 // the HBM latency; measured +15 % at C >= 256, +8 % on the k = 7 convs at C = 256, neutral at C = 128)
+                // pointwise convs: 256 positions x 128 channels per workgroup (64 accumulator registers per wave, 66 KiB of LDS) so
+                // that TWO workgroups share a CU - one's residual loads / stores run under the other's FMAs; with 512 positions
+                // (128 accumulator registers, 133 KiB) a CU runs one workgroup whose memory phases nothing overlaps
+                // (KALLE_CONV_K1_WIDE=1: the 512-position tile of rounds 1-2)
+                static const bool k1_wide = getenv("KALLE_CONV_K1_WIDE") && atoi(getenv("KALLE_CONV_K1_WIDE")) == 1;
+                if (ksize == 1 && Cout > 64 && !k1_wide) KALLE_CONV_V2N(16, 4, 8, 32, 256, 8);
                 if (ksize == 1 && Cout > 64) KALLE_CONV_V2N(16, 8, 8, 32, 512, 8);
+                // (the same halving for the wide k = 7 convs - 7 x the FMAs per byte - is worth 0.4 % of a decode: not taken)
                 if (ksize != 1 && Cout >= 256 && halo + 512 <= 640) KALLE_CONV_V2N(16, 8, 8, 8, 640, 8);
                 if (ksize == 1) KALLE_CONV_V2(16, 8, 4, 16, 512);   // pointwise conv: longer chunks cover the HBM latency
                 KALLE_CONV_V2(16, 8, 4, 8, 640);
