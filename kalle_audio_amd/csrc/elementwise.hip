@@ -2,6 +2,8 @@
 // accesses, grid-stride loops capped at 2048 blocks, fp32 math on bf16 storage.
 // Reference call sites are cited per kernel.
 #include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/kalle_hip.h"
 
@@ -540,7 +542,10 @@ extern "C" int kalle_adam_step(float* param, const float* grad, float* exp_avg, 
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     // 30 B / parameter of pure streaming: 16 k workgroups measured 4 % faster than the 2 k grid-stride default
-    const int agrid = (int)std::min<int64_t>(((n >> 2) + 255) / 256 + 1, 16384);
+    // (KALLE_ADAM_MAX_WGS: cap for runs that overlap the optimizer with GEMMs - 16 k workgroups take every wave slot of the chip
+    // and a 512-thread GEMM workgroup then waits for a CU to drain)
+    static const int max_wgs = getenv("KALLE_ADAM_MAX_WGS") ? atoi(getenv("KALLE_ADAM_MAX_WGS")) : 16384;
+    const int agrid = (int)std::min<int64_t>(((n >> 2) + 255) / 256 + 1, max_wgs > 0 ? max_wgs : 16384);
     KALLE_LAUNCH(adam_kernel, dim3(agrid), dim3(256), 0, static_cast<hipStream_t>(stream), param,
                        grad, exp_avg, exp_avg_sq, static_cast<bf16_t*>(param_bf16), n, lr, beta1, beta2, eps,
                        weight_decay, decoupled, bc1, bc2, grad_scale);
