@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <functional>
 #include <type_traits>
+#include <utility>
 
 #include "gemm_common.h"
 #include "../../include/kalle_hip.h"
@@ -77,6 +78,30 @@ struct Loader {
             __builtin_amdgcn_global_load_lds(GPTR(src[i]), LDS_PTR(void, region + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
             src[i] += kstep;
         }
+    }
+    // one piece (the software-pipelined 256 x 256 loop spreads a K-tile's pieces over its MFMA rows); `tail`: this is the ragged
+    // last K-tile (see issue_tail)
+    template <int I>
+    __device__ __forceinline__ void issue_one(char* region, int wave, int lane, bool tail, int kvalid) {
+        static_assert(I < PER_WAVE, "piece index");
+        const bf16_t* sp = src[I];
+        if (tail) {
+            const int q = wave * PER_WAVE + I;
+            bool ok;
+            if constexpr (!KM) {
+                const int row = 8 * q + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                ok = 8 * c < kvalid;
+            } else {
+                constexpr int RB = 2 * R, ROWS = 1024 / RB;
+                const int pos = q * ROWS + (lane * 16) / RB;
+                const int krow = (pos & ~7) | ((pos & 7) ^ (((pos >> 3) & 1) << 2));
+                ok = krow < kvalid;
+            }
+            if (!ok) sp = reinterpret_cast<const bf16_t*>(kalle_zero_block);
+        }
+        __builtin_amdgcn_global_load_lds(GPTR(sp), LDS_PTR(void, region + (wave * PER_WAVE + I) * 1024), 16, 0, 0);
+        src[I] += kstep;
     }
     // the ragged last K-tile (K % 64 != 0): only the first `kvalid` (a multiple of 8) of its 64 k exist; every piece that lies
     // beyond them is fetched from the zero block instead, so both operands contribute exact zeros there
@@ -148,6 +173,18 @@ struct Reader {
                 b0[s] = region_off + pos1 * RB + ((cl ^ (2 * (pos1 & 7))) << 4) + hb;
                 b1[s] = region_off + pos2 * RB + ((cl ^ (2 * (pos2 & 7))) << 4) + hb;
             }
+        }
+    }
+    static constexpr int NI = KM ? 2 : 1;    // LDS instructions per fragment
+    // ONE fragment: tile T (16 operand rows from rbase + 16 T) of k-step S, stage byte offset `so`
+    template <int S, int T>
+    __device__ __forceinline__ void read1(unsigned so, i32x4& f) const {
+        if constexpr (!KM) {
+            f = lds_b128<2048 * T>(b0[S] + so);
+        } else {
+            const i32x2 lo = lds_tr((b0[S] + so) ^ (T << 5));
+            const i32x2 hi = lds_tr((b1[S] + so) ^ (T << 5));
+            f = i32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     }
     // fragments of the 4 tiles (16 operand rows each) of k-step S, stage byte offset `so`
@@ -773,6 +810,25 @@ int launch2(const GemmParams& p, hipStream_t st) {
 // a wave reads the 12 fragments of a 32-deep k-step, waits, issues its 32 MFMAs; latency is covered by its SIMD
 // partner, which runs half a phase apart (second half of the workgroup defers the last MFMA block of a K-tile past
 // the barrier).  Per MFMA this tile needs 25 % fewer LDS reads, 33 % fewer DMA pieces and L2->LDS bytes than 256x128.
+// build switches: KALLE_GEMM_PIPE = 1 software-pipelined main loop (fragments refilled row by row; measured 3-4 % SLOWER over the
+// train step, 226.9 -> 235.4 ms same box: the loop is not waiting for LDS latency - on all-zero operands, i.e. at full clock, every
+// shape runs in the time of its LDS-DMA stream alone, on random operands the chip holds ~2.0 GHz - and spreading the DMA issue
+// over the second k-step halves the time the pieces have to land), 0 = the round-1 loop (default: whole k-step read in a burst,
+// SIMD partners half a phase apart, all DMA of K-tile kt + 2 issued right behind the hand-over); KALLE_GEMM_KNOCKOUT (variant builds for knock-out timing of the main
+// loop, tools/gemm_stamps.py): 1 no LDS-DMA after the prologue, 2 no fragment reads, 3 no MFMAs, 4 neither reads nor MFMAs
+#ifndef KALLE_GEMM_PIPE
+#define KALLE_GEMM_PIPE 0
+#endif
+#ifndef KALLE_GEMM_KNOCKOUT
+#define KALLE_GEMM_KNOCKOUT 0
+#endif
+#define KO_READ(...) do { if (KALLE_GEMM_KNOCKOUT != 2 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
+#define KO_MFMA(...) do { if (KALLE_GEMM_KNOCKOUT != 3 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 constexpr int GEMM3_LDS = 2 * (256 + 256) * 128 + 8 * 16 * 64 * 4;      // two 64-KiB stages + the epilogue patches = 160 KiB
 
 // compute units of the current device (cached per device ordinal)
@@ -825,7 +881,9 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
     ra.init(lds0, arow, lane);
     rb.init(lds0 + A_BYTES, bcol, lane);
     const bool late = wave >= NW / 2;     // the staggered half
+#if !KALLE_GEMM_PIPE
     if (late) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every issue arbitration by age otherwise
+#endif
 
     auto coords = [&](int tile, int& tm, int& tn) {
         if constexpr (XCD_RASTER) gemm_tile_coords(tile, ntiles_raster, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
@@ -876,6 +934,78 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
         __builtin_amdgcn_sched_barrier(0);
         gemm_stamp(p, wave, lane, 1, tile);
 
+#if KALLE_GEMM_PIPE
+        // ---- software-pipelined main loop (round 3): every wave keeps its own MFMA stream fed.  A k-step is 8 rows of 4 MFMAs
+        // (acc[r][0..3] += A_r x B_0..3); right behind row r the register of A_r is refilled with the NEXT k-step's A_r, and rows
+        // 0-3 also fetch the next k-step's B_r into the second B set - one or two LDS reads per 4 MFMAs instead of 12-24 reads in
+        // a burst that only the SIMD partner could cover; the 8 DMA pieces of K-tile kt + 2 go out one per row of the second
+        // k-step.  LDS reads return in order, so the waits are counted: before row 0 everything but the four youngest A
+        // fragments, before row r >= 1 everything up to A_r (= all but 7 A + 4 B fragments' worth of instructions; the counter
+        // has 4 bits).  One barrier per K-tile, at the k-step boundary: behind it the stage just read is free for the DMA of
+        // K-tile kt + 2 and the other stage (K-tile kt + 1, requested a K-tile ago) may be read.
+        i32x4 fa[8], fb[2][4];
+        constexpr int NIA = Reader<A_KM, BM>::NI, NIB = Reader<B_KM, BN>::NI;
+        constexpr int W0 = 4 * NIA < 15 ? 4 * NIA : 15;
+        constexpr int WR = 7 * NIA + 4 * NIB < 15 ? 7 * NIA + 4 * NIB : 15;
+        unsigned so_cur = s0;
+        int kt = 0;
+        // CUR: B set multiplied; RS: k-step whose fragments are fetched behind the rows (from stage so_rd); READ / WAIT / ISSUE:
+        // fetch at all / counted waits in front of the rows / DMA pieces of K-tile `kt_dma` into stage so_dma
+        auto kstep = [&](auto cur_c, auto rs_c, auto read_c, auto wait_c, auto issue_c, unsigned so_rd, unsigned so_dma, bool dma_tail) {
+            constexpr int CUR = decltype(cur_c)::value, RS = decltype(rs_c)::value;
+            constexpr bool READ = decltype(read_c)::value, WAIT = decltype(wait_c)::value;
+            constexpr bool ISSUE = decltype(issue_c)::value && KALLE_GEMM_KNOCKOUT != 1;
+            static_for<8>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (WAIT) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(r == 0 ? W0 : WR) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    KO_MFMA(acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[r]),
+                                                                                __builtin_bit_cast(bf16x8, fb[CUR][nt]), acc[r][nt], 0, 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ISSUE) {
+                    if constexpr (r < 4) la.template issue_one<r>(smem + so_dma, wave, lane, dma_tail, kvalid);
+                    else lb.template issue_one<r - 4>(smem + so_dma + A_BYTES, wave, lane, dma_tail, kvalid);
+                }
+                if constexpr (READ) {
+                    KO_READ(ra.template read1<RS, r>(so_rd, fa[r]));
+                    if constexpr (r < 4) KO_READ(rb.template read1<RS, r>(so_rd, fb[1 - CUR][r]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // prologue: k-step 0 of K-tile 0, in the issue order the counted waits assume
+        static_for<8>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            ra.template read1<0, r>(so_cur, fa[r]);
+            if constexpr (r < 4) rb.template read1<0, r>(so_cur, fb[0][r]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        auto iteration = [&](auto issue_c) {
+            kstep(I0{}, I1{}, T_{}, T_{}, F_{}, so_cur, 0u, false);
+            // hand-over: my reads of this stage have returned, my DMA pieces of K-tile kt + 1 have landed - and everybody's
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(I1{}, I0{}, T_{}, F_{}, issue_c, so_cur ^ STAGE, so_cur, kt + 2 == tail_t);
+            so_cur ^= STAGE;
+        };
+#pragma unroll 1
+        for (; kt + 2 < nk; ++kt) iteration(T_{});
+        if (kt + 1 < nk) { iteration(F_{}); ++kt; }
+        // the last K-tile: nothing to hand over (the epilogue's barrier follows)
+        kstep(I0{}, I1{}, T_{}, T_{}, F_{}, so_cur, 0u, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(I1{}, I0{}, F_{}, F_{}, F_{}, 0u, 0u, false);
+#else
         i32x4 fa[8], fb[4];
         unsigned so_cur = s0;
         int kt = 0;
@@ -885,11 +1015,6 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
 
         // (variant builds for knock-out timing of the main loop, tools/gemm_stamps.py: -DKALLE_GEMM_KNOCKOUT=1 no LDS-DMA after
         // the prologue, =2 no fragment reads, =3 no MFMAs, =4 neither reads nor MFMAs; the product build has none of it)
-#ifndef KALLE_GEMM_KNOCKOUT
-#define KALLE_GEMM_KNOCKOUT 0
-#endif
-#define KO_READ(...) do { if (KALLE_GEMM_KNOCKOUT != 2 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
-#define KO_MFMA(...) do { if (KALLE_GEMM_KNOCKOUT != 3 && KALLE_GEMM_KNOCKOUT != 4) { __VA_ARGS__; } } while (0)
         auto iteration = [&](auto issue_c, auto next_c) {
             constexpr bool ISSUE = decltype(issue_c)::value && KALLE_GEMM_KNOCKOUT != 1, NEXT = decltype(next_c)::value;
             // k-step 0 of this tile is in flight / landed
@@ -944,6 +1069,7 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
         // under the last MFMAs - 27 more VGPRs in the one-tile kernels, 33 spilled in the fused SwiGLU backward)
         if constexpr (!PERSIST || GLU == 2) iteration(F_{}, F_{});
         else last_iteration();
+#endif
         gemm_stamp(p, wave, lane, 2, tile);
 
         // Behind the epilogue's barrier both stages are free: request the next tile's K-tiles 0 and 1 there.  The loaders are

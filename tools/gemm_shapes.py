@@ -5,7 +5,13 @@ from kalle_audio_amd import ops
 dev = torch.device("cuda")
 lay = sys.argv[1]
 dims = list(map(int, sys.argv[2:]))
-mk = lambda r, c: (torch.randn(r, c, device=dev) * 0.5).bfloat16()
+# KALLE_SHAPE_ZEROS=1: all-zero operands (how far the chip's clock under load holds the kernel back);
+# KALLE_SHAPE_PAD=P: leading dimensions padded by P elements (address-to-channel effects of power-of-two-ish row strides)
+ZEROS = os.environ.get("KALLE_SHAPE_ZEROS") == "1"
+PAD = int(os.environ.get("KALLE_SHAPE_PAD", "0"))
+def mk(r, c):
+    t = torch.zeros(r, c + PAD, device=dev, dtype=torch.bfloat16) if ZEROS else (torch.randn(r, c + PAD, device=dev) * 0.5).bfloat16()
+    return t[:, :c] if PAD else t
 for i in range(0, len(dims), 3):
     M, N, K = dims[i:i + 3]
     if lay == "nt":
