@@ -478,6 +478,24 @@ int kalle_act1d_fwd(const void* x, void* y, int dtype, const float* filter12, co
 int kalle_snake_beta_fwd(const void* x, void* y, int dtype, const float* alpha, const float* beta, int logscale,
                          int B, int C, int L, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Off-default options of the DiT's transformer (none is set by the configs the reference ships)
+ */
+/* x[b][i] += table[i], b < nbatch, i < n: the position-embedding add of ContinuousTransformer(use_sinusoidal_emb /
+ * use_abs_pos_emb), transformer.py:796-797 (`x = x + self.pos_emb(x)`, one [seq][dim] table for every batch element).
+ * fp32, n % 4 == 0, 16-byte aligned; in place on the residual stream */
+int kalle_add_rows(float* x, const float* table, int64_t nbatch, int64_t n, void* stream);
+/* depthwise convolution along the sequence of token-major activations - ConformerModule.depthwise_conv, transformer.py:564
+ * (Conv1d(dim, dim, 17, groups = dim, padding = 8, bias = False) between two rearranges b n d <-> b d n, 576-578):
+ *   y[b][n][c] = sum_k w[c][flip ? K-1-k : k] * x[b][n + k - pad][c]        (x = 0 outside 0 <= n + k - pad < N)
+ * x: bf16 [B][N][D]; w: fp32 [D][K] (the parameter's [D][1][K]); y: fp32 or bf16 [B][N][D].  flip != 0 with
+ * pad = K - 1 - padding is the data gradient (x = dy).  D even, K <= 32, B <= 65535 */
+int kalle_dwconv1d_fwd(const void* x, const float* w, void* y, int y_dtype, int B, int N, int D, int K, int pad, int flip,
+                       void* stream);
+/* its weight gradient: dw[c][k] += sum_{b, n} dy[b][n][c] * x[b][n + k - pad][c]   (dy, x bf16; dw fp32 [D][K], atomically
+ * ADDED into: zero it for a fresh sum) */
+int kalle_dwconv1d_wgrad(const void* dy, const void* x, float* dw, int B, int N, int D, int K, int pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

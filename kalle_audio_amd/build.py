@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkalle_hip.so")
 SOURCES = ["gemm.hip", "gemm2.hip", "norm.hip", "elementwise.hip", "attention.hip", "conv1d.hip", "conv1d_bwd.hip",
-           "llasa.hip"]
+           "llasa.hip", "conformer.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-value"]
 

@@ -75,6 +75,13 @@ class GradOut:
             self.touched.add(self.prefix + name)
         return s
 
+    def _sink2d(self, name, dy, x):
+        """the sink of a weight gradient as the [N, K] matrix the GEMM writes (a 1 x 1 conv weight is stored [N, K, 1])"""
+        s = self._sink(name)
+        if s is not None and s.dim() != 2:
+            s = s.view(dy.shape[1], x.shape[1])
+        return s
+
     def zero_unwritten(self):
         """Sinks that NO kernel of this backward pass wrote - the cross-attention of a block called with context=None
         (transformer.py:684-693 skips it), a sub-module that only runs in a later micro-batch - must read as zero when the
@@ -106,7 +113,7 @@ class GradOut:
         # group (adaLN step 255 -> 265 ms): it keeps its own GEMM
         most = max(dy.shape[0] for _, dy, _ in items)
         for name, dy, x in [it for it in items if it[1].shape[0] * 8 < most]:
-            s = self._sink(name)
+            s = self._sink2d(name, dy, x)
             if s is not None:
                 ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=not over)
                 self.grads[name] = None
@@ -114,7 +121,7 @@ class GradOut:
                 self.grads[name] = ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out_dtype=F32)
         items = [it for it in items if it[1].shape[0] * 8 >= most]
         for name, dy, x in items:
-            s = self._sink(name)
+            s = self._sink2d(name, dy, x)
             if s is not None:
                 out = s
                 self.grads[name] = None
@@ -131,7 +138,7 @@ class GradOut:
                 and dy.data_ptr() % 16 == 0 and x.is_contiguous()):        # (dy may be a column slice: the kernels take ld)
             self.deferred.append((name, dy, x))
             return
-        s = self._sink(name)
+        s = self._sink2d(name, dy, x)
         if s is not None:
             ops.gemm(dy, x, a_kmajor=True, b_kmajor=True, out=s, accumulate=self.accumulate and not self.wgrad_overwrite)
             self.grads[name] = None
@@ -205,9 +212,10 @@ def _qk_norm_bwd(go, pre, qkn, which, x, ldx, x_off, stat, g, dx, lddx, dx_off, 
     ops.head_norm_bwd(x, ldx, x_off, stat, g, dx, lddx, dx_off, rows, heads, mode, gamma, dga, dbe)
 
 
-def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, out_dtype=F32, qkn=None):
+def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, out_dtype=F32, qkn=None, causal=False):
     """transformer.py:419-420, 430-444, 500/514-530, 541-545.  h: bf16 [B*N, D].  qkn: qk_norm_params()"""
     D = H * 64
+    causal = bool(causal) and N > 1                      # :468-469
     qkv = ops.gemm(h, wqkv)
     nrm = None
     if qkn is not None:     # :422-428, before the rotary embedding (which the attention kernel applies)
@@ -215,19 +223,20 @@ def self_attn_fwd(h, wqkv, wo, B, N, H, rope, mask8, residual=None, gate=None, o
         kn, ks = ops.head_norm_fwd(qkv, 3 * D, D, B * N, H, qkn[0], qkn[3], qkn[4])
         nrm = (qn, qs, kn, ks)
         ao, lse = ops.attention_fwd(qn, kn, qkv, ldq=D, q_off=0, ldk=D, k_off=0, ldv=3 * D, v_off=2 * D,
-                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8, causal=causal)
     else:
         ao, lse = ops.attention_fwd(qkv, qkv, qkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D, ldv=3 * D, v_off=2 * D,
-                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+                                    B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8, causal=causal)
     out = ops.gemm(ao.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, gate=gate, rows_per_batch=N,
                    row_mask=mask8)
     return out, (qkv, ao, lse, nrm)
 
 
-def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_attn.", qkn=None):
+def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_attn.", qkn=None, causal=False):
     """gb: bf16 [B*N, D] gradient w.r.t. the to_out GEMM result. Returns dh (bf16)."""
     qkv, ao, lse, nrm = saved
     D = H * 64
+    causal = bool(causal) and N > 1
     go.wgrad(pre + "to_out.weight", gb, ao.view(B * N, D))
     dao = dgrad(gb, wo)
     dqkv = torch.empty_like(qkv)
@@ -235,12 +244,12 @@ def self_attn_bwd(go, gb, h, saved, wqkv, wo, B, N, H, rope, mask8, pre="self_at
         qn, qs, kn, ks = nrm
         dqn, dkn = torch.empty_like(qn), torch.empty_like(kn)
         ops.attention_bwd(qn, kn, qkv, ao, dao, lse, dqn, dkn, dqkv, ldq=D, q_off=0, ldk=D, k_off=0,
-                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8, causal=causal)
         _qk_norm_bwd(go, pre, qkn, "q_norm", qkv, 3 * D, 0, qs, dqn, dqkv, 3 * D, 0, B * N, H)
         _qk_norm_bwd(go, pre, qkn, "k_norm", qkv, 3 * D, D, ks, dkn, dqkv, 3 * D, D, B * N, H)
     else:
         ops.attention_bwd(qkv, qkv, qkv, ao, dao, lse, dqkv, dqkv, dqkv, ldq=3 * D, q_off=0, ldk=3 * D, k_off=D,
-                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8)
+                          ldv=3 * D, v_off=2 * D, B=B, H=H, Hkv=H, Nq=N, Nk=N, rope=rope, key_mask=mask8, causal=causal)
     go.wgrad(pre + "to_qkv.weight", dqkv, h)
     return dgrad(dqkv, wqkv)
 
@@ -286,17 +295,18 @@ class ContextKV:
 
 
 def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_dtype=F32, row_mask=None, qkn=None,
-                   ckv=None, layer_ix=0):
+                   ckv=None, layer_ix=0, causal=False):
     """transformer.py:411-416, 505-508 (GQA), 541.  h: bf16 [B*N, D]; ctx: bf16 [B*S, Dc].  ckv: ContextKV of the enclosing
     ContinuousTransformer (then this layer's k | v are columns of ckv.kv and no projection runs here)."""
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
+    causal = bool(causal) and N > 1                      # :468-469; query r sees keys c <= r + S - N (create_causal_mask, :32)
     q = ops.gemm(h, wq)
     if ckv is not None and qkn is None:
         off = layer_ix * 2 * Dc
         co, lse = ops.attention_fwd(q, ckv.kv, ckv.kv, ldq=D, q_off=0, ldk=ckv.ld, k_off=off, ldv=ckv.ld, v_off=off + Dc,
-                                    B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                                    B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
         out = ops.gemm(co.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, row_mask=row_mask)
         return out, (q, (ckv, off), co, lse, None)
     kv = ops.gemm(ctx, wkv)
@@ -306,21 +316,22 @@ def cross_attn_fwd(h, ctx, wq, wkv, wo, B, N, S, H, cmask8, residual=None, out_d
         kn, ks = ops.head_norm_fwd(kv, 2 * Dc, 0, B * S, Hkv, qkn[0], qkn[3], qkn[4])
         nrm = (qn, qs, kn, ks)
         co, lse = ops.attention_fwd(qn, kn, kv, ldq=D, q_off=0, ldk=Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
-                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
     else:
         co, lse = ops.attention_fwd(q, kv, kv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc, v_off=Dc, B=B, H=H,
-                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                                    Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
     out = ops.gemm(co.view(B * N, D), wo, out_dtype=out_dtype, residual=residual, row_mask=row_mask)
     return out, (q, kv, co, lse, nrm)
 
 
 def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_acc=None, want_dctx=True,
-                   pre="cross_attn.", qkn=None):
+                   pre="cross_attn.", qkn=None, causal=False):
     """Returns dh (bf16), dctx (fp32 [B*S, Dc]; accumulated into dctx_acc when given; None if not wanted)."""
     q, kv, co, lse, nrm = saved
     D = H * 64
     Dc = ctx.shape[-1]
     Hkv = Dc // 64
+    causal = bool(causal) and N > 1
     go.wgrad(pre + "to_out.weight", gb, co.view(B * N, D))
     dco = dgrad(gb, wo)
     dq = torch.empty_like(q)
@@ -328,7 +339,7 @@ def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_
         ckv, off = kv
         dkv_all = ckv.grad_buffer()
         ops.attention_bwd(q, ckv.kv, ckv.kv, co, dco, lse, dq, dkv_all, dkv_all, ldq=D, q_off=0, ldk=ckv.ld, k_off=off,
-                          ldv=ckv.ld, v_off=off + Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                          ldv=ckv.ld, v_off=off + Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
         go.wgrad(pre + "to_q.weight", dq, h)
         dh = dgrad(dq, wq)
         go.wgrad(pre + "to_kv.weight", dkv_all[:, off:off + 2 * Dc], ctx)
@@ -338,12 +349,12 @@ def cross_attn_bwd(go, gb, h, ctx, saved, wq, wkv, wo, B, N, S, H, cmask8, dctx_
         qn, qs, kn, ks = nrm
         dkn = torch.empty_like(kn)
         ops.attention_bwd(qn, kn, kv, co, dco, lse, dq, dkn, dkv, ldq=D, q_off=0, ldk=Dc, k_off=0, ldv=2 * Dc,
-                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
         _qk_norm_bwd(go, pre, qkn, "q_norm", q, D, 0, qs, dq, dq, D, 0, B * N, H)          # in place over dq
         _qk_norm_bwd(go, pre, qkn, "k_norm", kv, 2 * Dc, 0, ks, dkn, dkv, 2 * Dc, 0, B * S, Hkv)
     else:
         ops.attention_bwd(q, kv, kv, co, dco, lse, dq, dkv, dkv, ldq=D, q_off=0, ldk=2 * Dc, k_off=0, ldv=2 * Dc,
-                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8)
+                          v_off=Dc, B=B, H=H, Hkv=Hkv, Nq=N, Nk=S, key_mask=cmask8, causal=causal)
     go.wgrad(pre + "to_q.weight", dq, h)
     dh = dgrad(dq, wq)
     go.wgrad(pre + "to_kv.weight", dkv, ctx)
@@ -385,6 +396,64 @@ def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff."):
     return dgrad(dhf, w1)
 
 
+# ------------------------------------------------------------------------------------------------ conformer module
+def conformer_params(mod):
+    """kernel-ready views of a ConformerModule (transformer.py:550-567); the 1 x 1 convolutions are plain matrices"""
+    c = SimpleNamespace()
+    D = mod.dim
+    c.g_in, c.beta_in = f32_of(mod.in_norm.gamma), _beta(mod.in_norm)
+    c.w_pw1 = bf16_of(mod.pointwise_conv.weight).view(D, D)
+    c.w_glu = bf16_of(mod.glu.proj.weight)
+    c.b_glu = f32_of(mod.glu.proj.bias)
+    c.w_dw = f32_of(mod.depthwise_conv.weight).view(D, -1)
+    c.pad = int(mod.depthwise_conv.padding[0])
+    c.g_mid, c.beta_mid = f32_of(mod.mid_norm.gamma), _beta(mod.mid_norm)
+    c.w_pw2 = bf16_of(mod.pointwise_conv_2.weight).view(D, D)
+    return c
+
+
+def conformer_fwd(c, x, B, N, residual=True):
+    """transformer.py:569-583 on token-major rows (the three rearranges b n d <-> b d n around the convolutions disappear: a
+    1 x 1 conv over channels is a GEMM over rows, the depthwise conv runs along the rows of a batch element).
+    x: fp32 [B*N, D].  Returns (x + conformer(x) when `residual` else conformer(x), saved)."""
+    D = x.shape[-1]
+    sv = SimpleNamespace(x=x)
+    sv.h0, sv.mean0, sv.rstd0 = ops.layernorm_fwd(x, c.g_in, c.beta_in)
+    sv.p1 = ops.gemm(sv.h0, c.w_pw1)
+    sv.hf = torch.empty((B * N, 2 * D), device=x.device, dtype=BF16)
+    sv.act = torch.empty((B * N, D), device=x.device, dtype=BF16)
+    if ops.gemm(sv.p1, c.w_glu, bias=c.b_glu, out=sv.hf, glu_mode=1, glu_inner=D, glu_aux=sv.act) is None:
+        ops.gemm(sv.p1, c.w_glu, bias=c.b_glu, out=sv.hf)
+        sv.act = ops.swiglu_fwd(sv.hf)
+    sv.cv = ops.dwconv1d(sv.act, c.w_dw, B, N, F32, c.pad)
+    sv.m, sv.mean1, sv.rstd1 = ops.layernorm_fwd(sv.cv, c.g_mid, c.beta_mid)
+    sv.s = ops.silu_fwd(sv.m)
+    y = ops.gemm(sv.s, c.w_pw2, out_dtype=F32, residual=x if residual else None)
+    return y, sv
+
+
+def conformer_bwd(go, c, sv, g, B, N, pre="conformer.", residual=True, gb=None, want_bf16=False):
+    """g: fp32 [B*N, D] gradient of the module's output (gb: the same rounded to bf16, if the caller has it).  Returns
+    (dx fp32 - including g itself when `residual` - , dx bf16 | None)."""
+    D = g.shape[-1]
+    K = c.w_dw.shape[1]
+    gb = gb if gb is not None else ops.cast(g, BF16)
+    go.wgrad(pre + "pointwise_conv_2.weight", gb, sv.s)
+    ds = dgrad(gb, c.w_pw2)
+    dm = ops.silu_bwd(ds, sv.m)
+    _, dcvb = go.ln(pre + "mid_norm.gamma", dm, sv.cv, c.g_mid, sv.mean1, sv.rstd1, want_bf16=True)
+    dact = ops.dwconv1d(dcvb, c.w_dw, B, N, BF16, K - 1 - c.pad, flip=True)
+    ops.dwconv1d_wgrad(dcvb, sv.act, go.bias_acc(pre + "depthwise_conv.weight", D * K, g.device).view(D, K), B, N, c.pad)
+    db = go.bias_acc(pre + "glu.proj.bias", 2 * D, g.device)
+    dhf = ops.swiglu_bwd(dact, sv.hf, db)
+    go.wgrad(pre + "glu.proj.weight", dhf, sv.p1)
+    dp1 = dgrad(dhf, c.w_glu)
+    go.wgrad(pre + "pointwise_conv.weight", dp1, sv.h0)
+    dh0 = dgrad(dp1, c.w_pw1)
+    return go.ln(pre + "in_norm.gamma", dh0, sv.x, c.g_in, sv.mean0, sv.rstd0, dres=g if residual else None,
+                 want_bf16=want_bf16)
+
+
 # ------------------------------------------------------------------------------------------------ transformer block
 def _beta(norm):
     b = getattr(norm, "beta", None)
@@ -421,6 +490,8 @@ def block_params(blk):
     p.layer_ix = getattr(blk, "layer_ix", 0)
     p.qkn_s = qk_norm_params(blk.self_attn)
     p.qkn_c = qk_norm_params(blk.cross_attn) if p.cross else None
+    p.causal = bool(getattr(blk, "causal", False))
+    p.conf = conformer_params(blk.conformer) if getattr(blk, "conformer", None) is not None else None
     return p
 
 
@@ -430,7 +501,10 @@ BLOCK_PARAM_ORDER = ("pre_norm.gamma", "self_attn.to_qkv.weight", "self_attn.to_
                      "ff.ff.2.weight", "ff.ff.2.bias", "to_scale_shift_gate.1.weight",
                      "self_attn.q_norm.weight", "self_attn.q_norm.bias", "self_attn.k_norm.weight", "self_attn.k_norm.bias",
                      "cross_attn.q_norm.weight", "cross_attn.q_norm.bias", "cross_attn.k_norm.weight",
-                     "cross_attn.k_norm.bias")
+                     "cross_attn.k_norm.bias",
+                     "conformer.in_norm.gamma", "conformer.pointwise_conv.weight", "conformer.glu.proj.weight",
+                     "conformer.glu.proj.bias", "conformer.depthwise_conv.weight", "conformer.mid_norm.gamma",
+                     "conformer.pointwise_conv_2.weight")
 
 
 def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S, ckv=None):
@@ -448,15 +522,21 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S, ckv=None):
         sc_s, sh_s, g_s, sc_f, sh_f, g_f = (sv.mod[:, i * D:(i + 1) * D] for i in range(6))
     # self-attention
     sv.h1, sv.mean1, sv.rstd1 = ops.layernorm_fwd(x, p.g1, p.beta1, sc_s, sh_s, rows_per_batch=N)
-    sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s, qkn=p.qkn_s)
+    sv.x1, sv.sa = self_attn_fwd(sv.h1, p.wqkv, p.wo, B, N, p.H, rope, mask8, residual=x, gate=g_s, qkn=p.qkn_s,
+                                 causal=p.causal)
     xcur = sv.x1
     # cross-attention (never modulated, 670-671)
     sv.has_cross = p.cross and ctx is not None
     if sv.has_cross:
         sv.h2, sv.mean2, sv.rstd2 = ops.layernorm_fwd(xcur, p.g2, p.beta2)
         sv.x2, sv.ca = cross_attn_fwd(sv.h2, ctx, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, residual=xcur, qkn=p.qkn_c,
-                                      ckv=ckv, layer_ix=p.layer_ix)
+                                      ckv=ckv, layer_ix=p.layer_ix, causal=p.causal)
         xcur = sv.x2
+    # conformer module (673-674 / 691-692: x = x + conformer(x), never modulated)
+    sv.cf = None
+    if p.conf is not None:
+        sv.xc, sv.cf = conformer_fwd(p.conf, xcur, B, N)
+        xcur = sv.xc
     # feed-forward
     sv.h3, sv.mean3, sv.rstd3 = ops.layernorm_fwd(xcur, p.g3, p.beta3, sc_f, sh_f, rows_per_batch=N)
     y, sv.ff = ff_fwd(sv.h3, p.w1, p.b1, p.w2, p.b2, N, residual=xcur, gate=g_f)
@@ -477,7 +557,7 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
     sl = (lambda i: mod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
     dmod = torch.empty_like(mod) if ada else None
     dsl = (lambda i: dmod[:, i * D:(i + 1) * D]) if ada else (lambda i: None)
-    xin_ff = sv.x2 if sv.has_cross else sv.x1
+    xin_ff = sv.xc if sv.cf is not None else (sv.x2 if sv.has_cross else sv.x1)
 
     # ---- feed-forward branch:  y = xin_ff + FF(LN(xin_ff)*(1+sc)+sh) * sigmoid(1-gate)
     if ada:
@@ -492,11 +572,14 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         dsl(4).copy_(dsh)
     g2, g2b = go.ln("ff_norm.gamma", dh3, xin_ff, p.g3, sv.mean3, sv.rstd3, scale=sl(3), rows_per_batch=N, dres=g,
                     want_bf16=True)
+    # ---- conformer module
+    if sv.cf is not None:
+        g2, g2b = conformer_bwd(go, p.conf, sv.cf, g2, B, N, gb=g2b, want_bf16=True)
     # ---- cross-attention branch
     dctx = None
     if sv.has_cross:
         dh2, dctx = cross_attn_bwd(go, g2b, sv.h2, ctx, sv.ca, p.wq, p.wkv, p.wo2, B, N, S, p.H, cmask8, dctx_acc,
-                                   want_dctx, qkn=p.qkn_c)
+                                   want_dctx, qkn=p.qkn_c, causal=p.causal)
         g1, g1bf = go.ln("cross_attend_norm.gamma", dh2, sv.x1, p.g2, sv.mean2, sv.rstd2, dres=g2,
                          want_bf16=not ada and mask8 is None)
     else:
@@ -509,7 +592,7 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         g1b, _ = ops.grad_cast(g1, B, N, row_mask=mask8)
     else:
         g1b = g1bf if g1bf is not None else ops.cast(g1, BF16)
-    dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8, qkn=p.qkn_s)
+    dh1 = self_attn_bwd(go, g1b, sv.h1, sv.sa, p.wqkv, p.wo, B, N, p.H, rope, mask8, qkn=p.qkn_s, causal=p.causal)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
         dsl(0).copy_(dsc)

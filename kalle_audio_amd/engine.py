@@ -136,7 +136,9 @@ class FlatBuckets:
             members = [(n, p) for n, p in named_params if bucket_of(n) == k]
             for want_small in (True, False):
                 for n, p in members:
-                    if (p.dim() < 2) != want_small:
+                    # (`_kalle_atomic_grad`: a tensor of >= 2 dims whose gradient kernel ADDS into the sink - the depthwise taps of
+                    # a ConformerModule - travels with the vectors, i.e. in the range that is cleared every step)
+                    if (p.dim() < 2 or getattr(p, "_kalle_atomic_grad", False)) != want_small:
                         continue
                     self.slices[n] = (off, p.numel())
                     off += (p.numel() + align - 1) // align * align

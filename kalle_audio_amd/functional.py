@@ -249,6 +249,58 @@ class SpliceFn(torch.autograd.Function):
         return dpre, dtok.to(tdt)
 
 
+class AddRowsFn(torch.autograd.Function):
+    """x + table for every batch element (the position embedding of a ContinuousTransformer, transformer.py:796-797).  x: the fp32
+    residual stream [B, N, D] (a fresh tensor from SpliceFn: updated in place), table: [N, D]; the table's gradient is the sum
+    of the incoming gradient over the batch (kalle_colsum over [B, N*D])."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        tab = _to_f32(table.contiguous())
+        if x.dtype == F32 and x.is_contiguous() and not x.is_leaf:
+            ctx.mark_dirty(x)
+            out = x
+        else:
+            xf = _to_f32(x.contiguous())
+            out = ops.axpby(xf, xf, 1.0, 0.0)
+        ops.add_rows(out, tab)
+        ctx.tdt = table.dtype
+        ctx.tshape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dt = None
+        if ctx.needs_input_grad[1]:
+            gf = _to_f32(g.contiguous())
+            dt = ops.colsum(gf.view(gf.shape[0], -1)).view(ctx.tshape).to(ctx.tdt)
+        return g, dt
+
+
+class ConformerFn(torch.autograd.Function):
+    """Stand-alone ConformerModule (transformer.py:550-583): no residual (the block adds it, 673-674)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        B, N, Dm = x.shape
+        xin = _to_f32(x.contiguous()).view(B * N, Dm)
+        y, sv = D.conformer_fwd(D.conformer_params(mod), xin, B, N, residual=False)
+        ctx.mod, ctx.sv, ctx.dims, ctx.xdt = mod, sv, (B, N, Dm), x.dtype
+        ctx.names = [n for n, _ in mod.named_parameters()]
+        return _like(y, x.dtype if x.dtype in (F32, BF16) else F32).view(B, N, Dm)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, Dm = ctx.dims
+        go = D.GradOut()
+        gf = _to_f32(g.contiguous()).view(B * N, Dm)
+        dx, _ = D.conformer_bwd(go, D.conformer_params(ctx.mod), ctx.sv, gf, B, N, pre="", residual=False)
+        ctx.sv = None
+        have = dict(ctx.mod.named_parameters())
+        pg = tuple(go.grads[n].view(have[n].shape) for n in ctx.names)
+        return (None, _like(dx, ctx.xdt if ctx.xdt in (F32, BF16) else F32).view(B, N, Dm)) + pg
+
+
 # bf16 shadows of residual-stream gradients handed from block i+1's backward to block i's: keyed by the fp32 gradient's
 # address and tagged with the producing layer.  The entry keeps a reference to the fp32 gradient itself, so (a) its address
 # cannot be recycled for another tensor while the entry lives and (b) autograd can never add a second consumer's gradient
@@ -357,6 +409,9 @@ class TransformerBlockFn(torch.autograd.Function):
             dglobal = None
         names = blk._kalle_param_names
         pg = tuple(gr.get(n) for n in names)
+        if getattr(blk, "conformer", None) is not None:      # conv weights are [out, in / groups, k]: the kernels wrote matrices
+            have = dict(blk.named_parameters())
+            pg = tuple(g_ if g_ is None else g_.view(have[n].shape) for n, g_ in zip(names, pg))
         return (None, dx, dctx, dglobal, None, None, None) + pg
 
 
@@ -382,9 +437,10 @@ class AttentionFn(torch.autograd.Function):
     """Stand-alone Attention module (transformer.py:396-547): projections + fused attention + to_out."""
 
     @staticmethod
-    def forward(ctx, mod, x, context, mask8, cmask8, rope, *params):
+    def forward(ctx, mod, x, context, mask8, cmask8, rope, causal, *params):
         B, N, Dm = x.shape
         H = mod.num_heads
+        ctx.causal = causal
         h = _to_bf16(x.contiguous()).view(B * N, Dm)
         cross = hasattr(mod, "to_q")
         odt = F32 if x.dtype == F32 else BF16
@@ -395,11 +451,11 @@ class AttentionFn(torch.autograd.Function):
             km = cmask8 if context is not None else mask8
             out, sv = D.cross_attn_fwd(h, cb, D.bf16_of(mod.to_q.weight), D.bf16_of(mod.to_kv.weight),
                                        D.bf16_of(mod.to_out.weight), B, N, S, H, km, out_dtype=odt, row_mask=mask8,
-                                       qkn=D.qk_norm_params(mod))
+                                       qkn=D.qk_norm_params(mod), causal=causal)
             ctx.extra = (cb, S, km, context is not None)
         else:
             out, sv = D.self_attn_fwd(h, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight), B, N, H, rope,
-                                      mask8, out_dtype=odt, qkn=D.qk_norm_params(mod))
+                                      mask8, out_dtype=odt, qkn=D.qk_norm_params(mod), causal=causal)
             ctx.extra = None
         ctx.mod, ctx.h, ctx.sv, ctx.cross = mod, h, sv, cross
         ctx.meta = (B, N, Dm, H, mask8, rope, x.dtype, context.dtype if context is not None else None,
@@ -420,7 +476,7 @@ class AttentionFn(torch.autograd.Function):
             go = D.GradOut()
             dh, dctx = D.cross_attn_bwd(go, gb, ctx.h, cb, ctx.sv, D.bf16_of(mod.to_q.weight),
                                         D.bf16_of(mod.to_kv.weight), D.bf16_of(mod.to_out.weight), B, N, S, H, km,
-                                        pre="", qkn=D.qk_norm_params(mod))
+                                        pre="", qkn=D.qk_norm_params(mod), causal=ctx.causal)
             dwq, dwkv, dwo = go.grads["to_q.weight"], go.grads["to_kv.weight"], go.grads["to_out.weight"]
             dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
             dc = None
@@ -428,13 +484,13 @@ class AttentionFn(torch.autograd.Function):
                 dc = dctx.view(cshape).to(cdt)
             else:
                 dx = dx + dctx.view(B, N, Dm).to(dx.dtype)  # kv_input == x: tape-level add of two input gradients
-            return (None, dx, dc, None, None, None, dwq, dwkv, dwo) + _qk_norm_grads(mod, go)
+            return (None, dx, dc, None, None, None, None, dwq, dwkv, dwo) + _qk_norm_grads(mod, go)
         go = D.GradOut()
         dh = D.self_attn_bwd(go, gb, ctx.h, ctx.sv, D.bf16_of(mod.to_qkv.weight), D.bf16_of(mod.to_out.weight),
-                             B, N, H, rope, mask8, pre="", qkn=D.qk_norm_params(mod))
+                             B, N, H, rope, mask8, pre="", qkn=D.qk_norm_params(mod), causal=ctx.causal)
         dwqkv, dwo = go.grads["to_qkv.weight"], go.grads["to_out.weight"]
         dx = _like(dh, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
-        return (None, dx, None, None, None, None, dwqkv, dwo) + _qk_norm_grads(mod, go)
+        return (None, dx, None, None, None, None, None, dwqkv, dwo) + _qk_norm_grads(mod, go)
 
 
 def _qk_norm_grads(mod, go):

@@ -443,6 +443,38 @@ def axpby(x, y, a, b, out=None):
     return out
 
 
+def add_rows(x, table):
+    """x[b] += table for every batch element b, in place (transformer.py:796-797); x fp32 [B, ...] contiguous, table fp32 with
+    the element count of x[0]"""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and table.dtype == torch.float32 and x.is_contiguous() and table.is_contiguous()
+    assert x[0].numel() == table.numel()
+    check(lib.kalle_add_rows(_p(x), _p(table), x.shape[0], table.numel(), _stream()), "kalle_add_rows")
+    return x
+
+
+def dwconv1d(x, w, B, N, out_dtype, pad, flip=False):
+    """depthwise conv along the sequence of token-major bf16 activations [B * N, D] (ConformerModule, transformer.py:564);
+    w fp32 [D, K]; flip=True with pad = K - 1 - padding is the data gradient"""
+    lib = _lib.load()
+    D, K = w.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    assert x.numel() == B * N * D
+    y = torch.empty((B * N, D), device=x.device, dtype=out_dtype)
+    check(lib.kalle_dwconv1d_fwd(_p(x), _p(w), _p(y), _dt(y), B, N, D, K, pad, int(flip), _stream()), "kalle_dwconv1d_fwd")
+    return y
+
+
+def dwconv1d_wgrad(dy, x, dw, B, N, pad):
+    """dw [D, K] fp32 += sum_{b, n} dy[b, n, :, None] * x[b, n + k - pad, :, None]   (atomic adds)"""
+    lib = _lib.load()
+    D, K = dw.shape
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.numel() == B * N * D == x.numel()
+    check(lib.kalle_dwconv1d_wgrad(_p(dy), _p(x), _p(dw), B, N, D, K, pad, _stream()), "kalle_dwconv1d_wgrad")
+    return dw
+
+
 def embed_mix_fwd(ids, table, audio, ids_mask, audio_mask):
     """ids [rows] int64, table fp32 [V, D], audio fp32/bf16 [rows, D], masks fp32 [rows] -> fp32 [rows, D]"""
     lib = _lib.load()

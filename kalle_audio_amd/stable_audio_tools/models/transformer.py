@@ -2,9 +2,11 @@
 constructor kwargs, forward signatures and state-dict keys; every forward runs the hand-written gfx950 kernels
 (kalle_audio_amd/csrc) through autograd shims.  GPU tensors only - there is no CPU or torch-math fallback.
 
-Not carried over (raise NotImplementedError when requested): causal attention, natten neighbourhood
-attention, conv feed-forward, ConformerModule, sinusoidal/absolute position embeddings - none is reachable from
-the DiT path (dit.py:107-125) with the configs the reference ships.
+Off-default options carried over in round 3 (none is reachable from the DiT path, dit.py:107-125, with the configs the
+reference ships): ConformerModule (`conformer=True`), ScaledSinusoidalEmbedding / AbsolutePositionalEmbedding
+(`use_sinusoidal_emb` / `use_abs_pos_emb`), `causal=True` (parity unpinned: the reference's own causal calls raise, see
+Attention).  Not carried over (raise NotImplementedError when requested): natten neighbourhood attention, conv feed-forward,
+remove_norms, use_xpos.
 """
 import os
 
@@ -42,6 +44,48 @@ class RotaryEmbedding(nn.Module):
         t = t.to(torch.float32) / self.interpolation_factor
         freqs = t[:, None] * self.inv_freq[None, :].float()
         return torch.cat((freqs, freqs), dim=-1), 1.
+
+
+class AbsolutePositionalEmbedding(nn.Module):
+    """transformer.py:45-65: a learned table, scaled by dim^-0.5 (returns the [n, dim] table of positions 0..n-1; the add to the
+    sequence is ContinuousTransformer's, 796-797)."""
+
+    def __init__(self, dim, max_seq_len):
+        super().__init__()
+        self.scale = dim ** -0.5
+        self.max_seq_len = max_seq_len
+        self.emb = nn.Embedding(max_seq_len, dim)
+
+    def forward(self, x, pos=None, seq_start_pos=None):
+        seq_len = x.shape[1]
+        assert seq_len <= self.max_seq_len, (f"you are passing in a sequence length of {seq_len} but your absolute positional "
+                                             f"embedding has a max sequence length of {self.max_seq_len}")
+        if pos is None:
+            pos = torch.arange(seq_len, device=x.device)
+        if seq_start_pos is not None:
+            pos = (pos - seq_start_pos[..., None]).clamp(min=0)
+        return self.emb(pos) * self.scale       # table set-up on [n, dim] (the data-path add is kalle_add_rows)
+
+
+class ScaledSinusoidalEmbedding(nn.Module):
+    """transformer.py:67-87: cat(sin, cos)(pos x theta^(-i / (dim / 2))) times a learned scalar."""
+
+    def __init__(self, dim, theta=10000):
+        super().__init__()
+        assert (dim % 2) == 0, "dimension must be divisible by 2"
+        self.scale = nn.Parameter(torch.ones(1) * dim ** -0.5)
+        half_dim = dim // 2
+        freq_seq = torch.arange(half_dim).float() / half_dim
+        self.register_buffer("inv_freq", theta ** -freq_seq, persistent=False)
+
+    def forward(self, x, pos=None, seq_start_pos=None):
+        seq_len = x.shape[1]
+        if pos is None:
+            pos = torch.arange(seq_len, device=x.device)
+        if seq_start_pos is not None:
+            pos = pos - seq_start_pos[..., None]
+        emb = pos.float()[..., None] * self.inv_freq.float()
+        return torch.cat((emb.sin(), emb.cos()), dim=-1) * self.scale
 
 
 class LayerNorm(nn.Module):
@@ -105,13 +149,19 @@ class FeedForward(nn.Module):
 
 
 class Attention(nn.Module):
-    """transformer.py:271-547."""
+    """transformer.py:271-547.
+
+    causal: the mask of create_causal_mask (transformer.py:32-33) - query r attends keys c <= r + (keys - queries), a single
+    query attends everything (468-469) - applied inside the attention kernels (forward and both backward passes).  PARITY
+    UNPINNED for this flag: the reference calls the function as `self.create_causal_mask` (362, 372, 521), a name Attention
+    does not have, so its CPU branch raises AttributeError on every causal call and its GPU branch whenever a mask is given
+    or keys outnumber queries; the only causal call it completes is SDPA's is_causal on equal lengths, which is this mask."""
 
     def __init__(self, dim, dim_heads=64, dim_context=None, causal=False, zero_init_output=True, qk_norm='none',
                  natten_kernel_size=None):
         super().__init__()
-        if causal or natten_kernel_size is not None:
-            raise NotImplementedError("Attention(causal / natten): not on the DiT path (dit.py:252)")
+        if natten_kernel_size is not None:
+            raise NotImplementedError("Attention(natten): not on the DiT path (dit.py:252)")
         if qk_norm not in ("none", "l2", "ln"):
             raise ValueError(f"unknown qk_norm {qk_norm!r}")
         if dim_heads != 64:
@@ -138,8 +188,7 @@ class Attention(nn.Module):
 
     def forward(self, x, context=None, mask=None, context_mask=None, rotary_pos_emb=None, causal=None):
         _need_gpu(x)
-        if causal:
-            raise NotImplementedError("causal attention")
+        causal = self.causal if causal is None else causal
         rope = None
         if rotary_pos_emb is not None and context is None:
             freqs = rotary_pos_emb[0] if isinstance(rotary_pos_emb, (tuple, list)) else rotary_pos_emb
@@ -150,7 +199,29 @@ class Attention(nn.Module):
             params = (self.to_qkv.weight, self.to_out.weight)
         if self.qk_norm == "ln":
             params += (self.q_norm.weight, self.q_norm.bias, self.k_norm.weight, self.k_norm.bias)
-        return KF.AttentionFn.apply(self, x, context, KF._mask8(mask), KF._mask8(context_mask), rope, *params)
+        return KF.AttentionFn.apply(self, x, context, KF._mask8(mask), KF._mask8(context_mask), rope, bool(causal), *params)
+
+
+class ConformerModule(nn.Module):
+    """transformer.py:550-583: LayerNorm -> 1 x 1 conv -> GLU -> depthwise conv (k = 17) -> LayerNorm -> SiLU -> 1 x 1 conv.
+    Parameter names and shapes are the reference's (Conv1d weights [out, in / groups, k]); the math runs token-major in
+    dit_ops.conformer_fwd / conformer_bwd (the 1 x 1 convolutions are GEMMs, the depthwise one kalle_dwconv1d_*)."""
+
+    def __init__(self, dim, norm_kwargs={}):
+        super().__init__()
+        self.dim = dim
+        self.in_norm = LayerNorm(dim, **norm_kwargs)
+        self.pointwise_conv = nn.Conv1d(dim, dim, kernel_size=1, bias=False)
+        self.glu = GLU(dim, dim, nn.SiLU())
+        self.depthwise_conv = nn.Conv1d(dim, dim, kernel_size=17, groups=dim, padding=8, bias=False)
+        self.depthwise_conv.weight._kalle_atomic_grad = True    # (its gradient is ADDED into its sink: cleared with the vectors)
+        self.mid_norm = LayerNorm(dim, **norm_kwargs)
+        self.swish = nn.SiLU()
+        self.pointwise_conv_2 = nn.Conv1d(dim, dim, kernel_size=1, bias=False)
+
+    def forward(self, x):
+        _need_gpu(x)
+        return KF.ConformerFn.apply(self, x, *self.parameters())
 
 
 class TransformerBlock(nn.Module):
@@ -160,8 +231,8 @@ class TransformerBlock(nn.Module):
                  zero_init_branch_outputs=True, conformer=False, layer_ix=-1, remove_norms=False, attn_kwargs={},
                  ff_kwargs={}, norm_kwargs={}):
         super().__init__()
-        if conformer or remove_norms or causal:
-            raise NotImplementedError("TransformerBlock(conformer / remove_norms / causal)")
+        if remove_norms:
+            raise NotImplementedError("TransformerBlock(remove_norms)")
         self.dim = dim
         self.dim_heads = dim_heads
         self.cross_attend = cross_attend
@@ -177,7 +248,7 @@ class TransformerBlock(nn.Module):
         self.ff_norm = LayerNorm(dim, **norm_kwargs)
         self.ff = FeedForward(dim, zero_init_output=zero_init_branch_outputs, **ff_kwargs)
         self.layer_ix = layer_ix
-        self.conformer = None
+        self.conformer = ConformerModule(dim, norm_kwargs=norm_kwargs) if conformer else None
         self.global_cond_dim = global_cond_dim
         if global_cond_dim is not None:
             self.to_scale_shift_gate = nn.Sequential(nn.SiLU(), nn.Linear(global_cond_dim, dim * 6, bias=False))
@@ -200,8 +271,6 @@ class ContinuousTransformer(nn.Module):
                  zero_init_branch_outputs=True, conformer=False, use_sinusoidal_emb=False, use_abs_pos_emb=False,
                  abs_pos_emb_max_length=10000, **kwargs):
         super().__init__()
-        if use_sinusoidal_emb or use_abs_pos_emb or conformer or causal:
-            raise NotImplementedError("ContinuousTransformer(sinusoidal/abs pos emb, conformer, causal)")
         self.dim = dim
         self.depth = depth
         self.causal = causal
@@ -210,7 +279,11 @@ class ContinuousTransformer(nn.Module):
         self.project_out = nn.Linear(dim, dim_out, bias=False) if dim_out is not None else nn.Identity()
         self.rotary_pos_emb = RotaryEmbedding(max(dim_heads // 2, 32)) if rotary_pos_emb else None
         self.use_sinusoidal_emb = use_sinusoidal_emb
+        if use_sinusoidal_emb:
+            self.pos_emb = ScaledSinusoidalEmbedding(dim)
         self.use_abs_pos_emb = use_abs_pos_emb
+        if use_abs_pos_emb:
+            self.pos_emb = AbsolutePositionalEmbedding(dim, abs_pos_emb_max_length)
         for i in range(depth):
             self.layers.append(TransformerBlock(dim, dim_heads=dim_heads, cross_attend=cross_attend,
                                                 dim_context=cond_token_dim, global_cond_dim=global_cond_dim,
@@ -268,6 +341,8 @@ class ContinuousTransformer(nn.Module):
         else:
             x = KF.SpliceFn.apply(None, x)
         rotary = self.rotary_pos_emb.forward_from_seq_len(x.shape[1]) if self.rotary_pos_emb is not None else None
+        if self.use_sinusoidal_emb or self.use_abs_pos_emb:         # transformer.py:796-797
+            x = KF.AddRowsFn.apply(x, self.pos_emb(x))
         # transformer.py:800-802 calls every layer with rotary_pos_emb, global_cond and **kwargs only: the mask assembled above
         # is never handed to the layers, so padding masks do not reach the self-attention of a ContinuousTransformer (the
         # reference's behaviour, pinned by tests/golden/training_step.npz).  TransformerBlock / Attention called directly

@@ -80,9 +80,13 @@ def _sub(sd, prefix):
 
 
 # ---------------------------------------------------------------------------------------------- attention / FF
-def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, dim_heads=64, qk_l2=False):
+def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, dim_heads=64, qk_l2=False, causal=False):
     """transformer.py:396-547 (einsum / fp32-softmax branch 502-530, which is what the reference runs on CPU).
-    sd keys: to_qkv.weight | to_q.weight,to_kv.weight ; to_out.weight"""
+    sd keys: to_qkv.weight | to_q.weight,to_kv.weight ; to_out.weight
+    causal: the mask of create_causal_mask (transformer.py:32-33: ones(i, j).triu(j - i + 1), i.e. query r sees keys
+    c <= r + j - i), applied as 519-523 intend.  PARITY UNPINNED for this flag: the reference calls it as
+    `self.create_causal_mask` (362, 372, 521), a name Attention does not have, so every causal call on its CPU branch raises
+    AttributeError and no fixture can be produced."""
     B, N, D = x.shape
     h = D // dim_heads
     if "to_q.weight" in sd:
@@ -114,6 +118,9 @@ def attention(sd, x, context=None, mask=None, context_mask=None, rotary=None, di
     dots = (q @ k.transpose(-1, -2)) * (dim_heads ** -0.5)
     if in_mask is not None:
         dots = dots.masked_fill(~in_mask[:, None, None, :], -torch.finfo(dots.dtype).max)
+    if causal and dots.shape[-2] > 1:                 # 468-469: a single query is never masked
+        i, j = dots.shape[-2:]
+        dots = dots.masked_fill(torch.ones(i, j, dtype=torch.bool).triu(j - i + 1), -torch.finfo(dots.dtype).max)
     attn = dots.softmax(-1)
     out = (attn @ v).transpose(1, 2).reshape(B, N, D)
     out = linear(out, sd["to_out.weight"])
@@ -129,12 +136,34 @@ def feed_forward(sd, x):
     return linear(a * F.silu(g), sd["ff.2.weight"], sd["ff.2.bias"])
 
 
+_attention_impl = attention
+
+
+def conformer_module(sd, x):
+    """transformer.py:550-583 ConformerModule: LayerNorm -> 1x1 conv -> GLU (Linear D -> 2D with bias, x * silu(gate)) ->
+    depthwise Conv1d(k = 17, padding 8, no bias) along the sequence -> LayerNorm -> SiLU -> 1x1 conv.  x: [B, N, D];
+    keys in_norm.gamma, pointwise_conv.weight [D, D, 1], glu.proj.{weight,bias}, depthwise_conv.weight [D, 1, K],
+    mid_norm.gamma, pointwise_conv_2.weight [D, D, 1]"""
+    D = x.shape[-1]
+    h = layer_norm(x, sd["in_norm.gamma"], sd.get("in_norm.beta"))
+    h = linear(h, sd["pointwise_conv.weight"][:, :, 0])
+    a, g = linear(h, sd["glu.proj.weight"], sd["glu.proj.bias"]).chunk(2, -1)
+    h = a * F.silu(g)
+    w = sd["depthwise_conv.weight"]
+    h = F.conv1d(h.transpose(1, 2), w, None, padding=(w.shape[-1] - 1) // 2, groups=D).transpose(1, 2)
+    h = F.silu(layer_norm(h, sd["mid_norm.gamma"], sd.get("mid_norm.beta")))
+    return linear(h, sd["pointwise_conv_2.weight"][:, :, 0])
+
+
 def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_mask=None, rotary=None, dim_heads=64,
-                      qk_l2=False):
-    """transformer.py:649-695.  adaLN branch when the block has to_scale_shift_gate and global_cond is given."""
+                      qk_l2=False, causal=False):
+    """transformer.py:649-695.  adaLN branch when the block has to_scale_shift_gate and global_cond is given; the
+    ConformerModule (673-674 / 691-692) when the block has one; causal: see attention()."""
     ln = lambda pre, t: layer_norm(t, sd[pre + ".gamma"], sd.get(pre + ".beta"))
     sa = _sub(sd, "self_attn.")
     ff = _sub(sd, "ff.")
+    conf = _sub(sd, "conformer.")
+    attention = lambda *a, **k: _attention_impl(*a, causal=causal, **k)  # (Attention(causal=causal), 613-633)
     if "to_scale_shift_gate.1.weight" in sd and global_cond is not None:
         mod = linear(F.silu(global_cond), sd["to_scale_shift_gate.1.weight"]).unsqueeze(1)
         sc_s, sh_s, g_s, sc_f, sh_f, g_f = mod.chunk(6, -1)
@@ -145,6 +174,8 @@ def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_
         if context is not None:
             x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
                               context_mask=context_mask, dim_heads=dim_heads, qk_l2=qk_l2)
+        if conf:
+            x = x + conformer_module(conf, x)
         res = x
         hx = ln("ff_norm", x) * (1 + sc_f) + sh_f
         x = feed_forward(ff, hx) * torch.sigmoid(1 - g_f) + res
@@ -153,13 +184,26 @@ def transformer_block(sd, x, context=None, global_cond=None, mask=None, context_
         if context is not None:
             x = x + attention(_sub(sd, "cross_attn."), ln("cross_attend_norm", x), context=context,
                               context_mask=context_mask, dim_heads=dim_heads, qk_l2=qk_l2)
+        if conf:
+            x = x + conformer_module(conf, x)
         x = x + feed_forward(ff, ln("ff_norm", x))
     return x
 
 
+def scaled_sinusoidal_embedding(scale, n, dim, theta=10000.0):
+    """transformer.py:67-87 ScaledSinusoidalEmbedding: cat(sin, cos)(pos * theta^(-arange(dim/2) / (dim/2))) * scale"""
+    half = dim // 2
+    inv_freq = theta ** -(torch.arange(half).float() / half)
+    emb = torch.arange(n).float()[:, None] * inv_freq[None, :]
+    return torch.cat((emb.sin(), emb.cos()), -1) * scale
+
+
 def continuous_transformer(sd, x, depth, mask=None, prepend_embeds=None, prepend_mask=None, global_cond=None,
-                           context=None, context_mask=None, dim_heads=64):
-    """transformer.py:758-812: project_in, prepend (+mask cat 776-787), rotary over the full length, blocks, project_out."""
+                           context=None, context_mask=None, dim_heads=64, rotary=True, causal=False):
+    """transformer.py:758-812: project_in, prepend (+mask cat 776-787), rotary over the full length, the optional position
+    embedding added to the sequence (796-797: ScaledSinusoidalEmbedding when the state has pos_emb.scale,
+    AbsolutePositionalEmbedding 45-65 = emb.weight[arange(n)] * dim^-0.5 when it has pos_emb.emb.weight), blocks,
+    project_out."""
     B, T = x.shape[:2]
     if "project_in.weight" in sd:
         x = linear(x, sd["project_in.weight"])
@@ -170,13 +214,17 @@ def continuous_transformer(sd, x, depth, mask=None, prepend_embeds=None, prepend
             mask = mask if mask is not None else torch.ones(B, T, dtype=torch.bool)
             prepend_mask = prepend_mask if prepend_mask is not None else torch.ones(B, P, dtype=torch.bool)
             mask = torch.cat([prepend_mask, mask], -1)
-    rot = rotary_freqs(x.shape[1], max(dim_heads // 2, 32))
+    rot = rotary_freqs(x.shape[1], max(dim_heads // 2, 32)) if rotary else None
+    if "pos_emb.scale" in sd:
+        x = x + scaled_sinusoidal_embedding(sd["pos_emb.scale"], x.shape[1], x.shape[2])
+    elif "pos_emb.emb.weight" in sd:
+        x = x + sd["pos_emb.emb.weight"][:x.shape[1]] * x.shape[2] ** -0.5
     # transformer.py:800-802: the layers are called with rotary_pos_emb, global_cond and **kwargs (context, context_mask) -
     # the assembled `mask` is NOT handed on, so a padding mask never reaches the self-attention of a ContinuousTransformer
     # (pinned by tests/golden/training_step.npz, whose steps run with mask_padding=True)
     for i in range(depth):
         x = transformer_block(_sub(sd, f"layers.{i}."), x, context=context, global_cond=global_cond, mask=None,
-                              context_mask=context_mask, rotary=rot, dim_heads=dim_heads)
+                              context_mask=context_mask, rotary=rot, dim_heads=dim_heads, causal=causal)
     if "project_out.weight" in sd:
         x = linear(x, sd["project_out.weight"])
     return x
@@ -398,7 +446,14 @@ def pretransform_decode(sd, z, strides, use_snake, scale=1.0, final_tanh=True):
 
 
 # ---------------------------------------------------------------------------------------------- parameter shapes
-def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix="", qk_ln=False):
+def conformer_shapes(D, prefix="", K=17):
+    return [(prefix + "in_norm.gamma", (D,)), (prefix + "pointwise_conv.weight", (D, D, 1)),
+            (prefix + "glu.proj.weight", (2 * D, D)), (prefix + "glu.proj.bias", (2 * D,)),
+            (prefix + "depthwise_conv.weight", (D, 1, K)), (prefix + "mid_norm.gamma", (D,)),
+            (prefix + "pointwise_conv_2.weight", (D, D, 1))]
+
+
+def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix="", qk_ln=False, conformer=False):
     """(name, shape) list of one TransformerBlock (transformer.py:585-647); qk_ln: Attention(qk_norm="ln")'s LayerNorms"""
     qkn = lambda a: [(f"{prefix}{a}.{n}.{w}", (dim_heads,)) for n in ("q_norm", "k_norm") for w in ("weight", "bias")] if qk_ln else []
     s = [(prefix + "pre_norm.gamma", (D,)), (prefix + "self_attn.to_qkv.weight", (3 * D, D)),
@@ -410,6 +465,8 @@ def block_shapes(D, dim_heads=64, dim_context=None, global_cond_dim=None, prefix
     s += [(prefix + "ff_norm.gamma", (D,)), (prefix + "ff.ff.0.proj.weight", (8 * D, D)),
           (prefix + "ff.ff.0.proj.bias", (8 * D,)), (prefix + "ff.ff.2.weight", (D, 4 * D)),
           (prefix + "ff.ff.2.bias", (D,))]
+    if conformer:
+        s += conformer_shapes(D, prefix + "conformer.")
     if global_cond_dim:
         s += [(prefix + "to_scale_shift_gate.1.weight", (6 * D, global_cond_dim))]
     return s

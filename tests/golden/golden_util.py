@@ -115,6 +115,9 @@ def llasa_batch(lc, seed, B=3, L=40):
 # bench-width TransformerBlock (D = 1536, 24 heads, context 768 = 12 kv heads, 126 tokens, 130 context tokens)
 WIDE_BLOCK = dict(D=1536, DC=768, N=126, S=130, B=1)
 QK_NORM_BLOCK = dict(D=256, DC=128, N=40, S=24, B=2)
+# off-default block options (round 3): TransformerBlock(conformer=True) and ContinuousTransformer(use_sinusoidal_emb / use_abs_pos_emb)
+OPT_BLOCK = dict(D=256, DC=128, N=40, S=48, B=2)
+OPT_CT = dict(D=128, depth=2, dim_in=16, dim_out=16, N=37, P=3, B=2, max_len=64)
 
 # Llasa at 4 heads / 2 kv heads, sequences of ~300 with ragged right padding (30 s clips of configs/twj_0828.yaml are
 # 375 frames + text)

@@ -122,11 +122,11 @@ def test_unsupported_reference_options_raise():
     from kalle_audio_amd.stable_audio_tools.models import transformer as T
     from kalle_audio_amd.stable_audio_tools.models.dit import DiffusionTransformer
     with pytest.raises(NotImplementedError):
-        T.Attention(128, causal=True)
+        T.Attention(128, natten_kernel_size=7)
     with pytest.raises(ValueError):
         T.Attention(128, qk_norm="rms")
     with pytest.raises(NotImplementedError):
-        T.TransformerBlock(128, conformer=True)
+        T.TransformerBlock(128, remove_norms=True)
     with pytest.raises(NotImplementedError):
         DiffusionTransformer(transformer_type="x-transformers")
 
@@ -142,6 +142,17 @@ def test_optional_variants_keep_the_reference_parameter_names():
     assert not any("_norm" in k for k, _ in T.Attention(128, qk_norm="l2").named_parameters())
     d = {k: tuple(v.shape) for k, v in DecoderBlock(32, 16, stride=4, use_nearest_upsample=True).named_parameters()}
     assert d["layers.1.1.weight_v"] == (16, 32, 8) and d["layers.1.1.weight_g"] == (16, 1, 1) and "layers.1.1.bias" not in d
+    # round 3: TransformerBlock(conformer=True) (transformer.py:550-567) and the position embeddings of a ContinuousTransformer
+    # (transformer.py:45-87, 733-739) - names / shapes as the reference's own modules register them
+    b = {k: tuple(v.shape) for k, v in T.TransformerBlock(128, conformer=True, causal=True).named_parameters() if "conformer" in k}
+    assert b == {"conformer.in_norm.gamma": (128,), "conformer.pointwise_conv.weight": (128, 128, 1),
+                 "conformer.glu.proj.weight": (256, 128), "conformer.glu.proj.bias": (256,),
+                 "conformer.depthwise_conv.weight": (128, 1, 17), "conformer.mid_norm.gamma": (128,),
+                 "conformer.pointwise_conv_2.weight": (128, 128, 1)}
+    ct = T.ContinuousTransformer(dim=128, depth=1, use_sinusoidal_emb=True)
+    assert tuple(ct.pos_emb.scale.shape) == (1,) and "pos_emb.inv_freq" not in ct.state_dict()
+    ct = T.ContinuousTransformer(dim=128, depth=1, use_abs_pos_emb=True, abs_pos_emb_max_length=50)
+    assert tuple(ct.pos_emb.emb.weight.shape) == (50, 128)
 
 
 def test_reference_yaml_and_accelerate_configs_parse():

@@ -656,3 +656,72 @@ def test_transformer_block_qk_norm(kind, ada, seed):
                 assert np.abs(f[k]).max() < 1e-4 and sd[name].grad.abs().max() < 1e-4
             else:
                 close(sd[name].grad, f[k], 5e-5)
+
+
+@pytest.mark.parametrize("tag,ada,seed", [("conformer", False, 80), ("conformer_ada", True, 81)])
+def test_transformer_block_conformer(tag, ada, seed):
+    """TransformerBlock(conformer=True) (transformer.py:550-583, 673-674, 691-692): the block with its ConformerModule between
+    the cross-attention and the feed-forward, plain and adaLN, and the module on its own"""
+    f = fx("block_options")
+    o = gu.OPT_BLOCK
+    Do, DCo, No, So, Bo = o["D"], o["DC"], o["N"], o["S"], o["B"]
+    x = T(gu.make_input("x", (Bo, No, Do), seed), True)
+    ctx = T(gu.make_input("ctx", (Bo, So, DCo), seed), True)
+    dy = T(gu.make_input("dy", (Bo, No, Do), seed))
+    cmask = torch.arange(So)[None, :] < torch.tensor([So, So - 9])[:, None]
+    sd = state(ko.block_shapes(Do, dim_context=DCo, global_cond_dim=Do if ada else None, conformer=True), seed)
+    gc = T(gu.make_input("g", (Bo, Do), seed), True) if ada else None
+    y = ko.transformer_block(sd, x, context=ctx, context_mask=cmask, global_cond=gc, rotary=ko.rotary_freqs(No))
+    y.backward(dy)
+    close(y, f[f"{tag}/y"], 1e-5); close(x.grad, f[f"{tag}/dx"], 2e-5); close(ctx.grad, f[f"{tag}/dctx"], 2e-5)
+    if ada:
+        close(gc.grad, f[f"{tag}/dg"], 2e-5)
+    check_digests_n(f, sd, 32, prefix=f"{tag}/", tol=1e-4)
+    for k in f.files:
+        if k.startswith(f"{tag}/grad/"):
+            close(sd[k[len(tag) + 6:]].grad, f[k], 5e-5)
+    xm = T(gu.make_input("xm", (Bo, No, Do), seed), True)
+    ym = ko.conformer_module(ko._sub({k: v.detach() for k, v in sd.items()}, "conformer."), xm)
+    ym.backward(dy)
+    close(ym, f[f"{tag}/module_y"], 1e-5); close(xm.grad, f[f"{tag}/module_dx"], 2e-5)
+
+
+@pytest.mark.parametrize("tag,seed", [("ct_sin", 82), ("ct_abs", 83)])
+def test_continuous_transformer_position_embeddings(tag, seed):
+    """ContinuousTransformer(use_sinusoidal_emb / use_abs_pos_emb) (transformer.py:45-87, 733-739, 796-797): the embedding of
+    positions 0..n-1 (prepended tokens included) added to the projected sequence in front of the blocks"""
+    f = fx("block_options")
+    c = gu.OPT_CT
+    shapes = ko.continuous_transformer_shapes(c["D"], c["depth"], c["dim_in"], c["dim_out"])
+    shapes += [("pos_emb.scale", (1,))] if tag == "ct_sin" else [("pos_emb.emb.weight", (c["max_len"], c["D"]))]
+    sd = state(shapes, seed)
+    x = T(gu.make_input("x", (c["B"], c["N"], c["dim_in"]), seed), True)
+    pe = T(gu.make_input("prepend", (c["B"], c["P"], c["D"]), seed), True)
+    y = ko.continuous_transformer(sd, x, c["depth"], prepend_embeds=pe)
+    y.backward(T(gu.make_input("dy", tuple(y.shape), seed)))
+    close(y, f[f"{tag}/y"], 1e-5); close(x.grad, f[f"{tag}/dx"], 2e-5); close(pe.grad, f[f"{tag}/dprepend"], 2e-5)
+    check_digests_n(f, sd, 32, prefix=f"{tag}/", tol=1e-4)
+    for k in f.files:
+        if k.startswith(f"{tag}/grad/"):
+            close(sd[k[len(tag) + 6:]].grad, f[k], 5e-5)
+
+
+def test_attention_causal_mask_is_the_reference_function():
+    """Attention(causal=True): PARITY UNPINNED - the reference's CPU branch raises on every causal call (transformer.py:521
+    calls `self.create_causal_mask`, which is the module-level function of line 32).  The oracle applies that function's mask
+    (ones(i, j).triu(j - i + 1)) as lines 519-523 intend; this test holds the oracle to the definition: query r attends keys
+    c <= r + j - i only, a single query sees every key (468-469)."""
+    Dh = 64
+    sd = state([("to_q.weight", (Dh, Dh)), ("to_kv.weight", (2 * Dh, Dh)), ("to_out.weight", (Dh, Dh))], 90, False)
+    x = T(gu.make_input("x", (1, 5, Dh), 90))
+    ctx = T(gu.make_input("ctx", (1, 8, Dh), 90))
+    y = ko.attention(sd, x, context=ctx, causal=True)
+    for r in range(5):                      # row r must not change when the keys it cannot see change
+        c2 = ctx.clone()
+        c2[:, r + 8 - 5 + 1:] += 3.0
+        y2 = ko.attention(sd, x, context=c2, causal=True)
+        assert torch.allclose(y[:, r], y2[:, r], atol=1e-6)
+        if r + 8 - 5 + 1 < 8:
+            assert not torch.allclose(y[:, r + 1:], y2[:, r + 1:], atol=1e-6) or r == 4
+    one = ko.attention(sd, x[:, :1], context=ctx, causal=True)
+    close(one, ko.attention(sd, x[:, :1], context=ctx, causal=False), 1e-6)

@@ -418,3 +418,136 @@ def test_sampler_conditioning_hoisted_out_of_the_loop_is_bit_identical(dev, monk
     c = generate_diffusion_cond(m, **dict(kw, cfg_scale=1.0))               # unguided: no batch doubling
     monkeypatch.setenv("KALLE_SAMPLE_PRECOND", "0")
     assert torch.equal(c, generate_diffusion_cond(m, **dict(kw, cfg_scale=1.0)))
+
+
+# ------------------------------------------------------------------------------------------------ off-default block options
+def _opt_imports():
+    import golden_util as gu
+    from test_modules_gpu import T, fx, load_seeded
+    from test_round2_gpu import check_digests
+    from stable_audio_tools.models import transformer as mods
+    return gu, T, fx, load_seeded, check_digests, mods
+
+
+@pytest.mark.parametrize("tag,ada,seed", [("conformer", False, 80), ("conformer_ada", True, 81)])
+def test_transformer_block_conformer(dev, tag, ada, seed):
+    """TransformerBlock(conformer=True) (transformer.py:550-583, 673-674, 691-692) against the reference's own outputs
+    (tests/golden/block_options.npz): block output and input gradients within 1e-2 / 2e-2 (bf16 GEMM operands), every parameter
+    gradient by digest, the depthwise taps / norm scales / GLU bias of the ConformerModule in full; and the module on its own"""
+    gu, T, fx, load_seeded, check_digests, mods = _opt_imports()
+    f = fx("block_options")
+    o = gu.OPT_BLOCK
+    Do, DCo, No, So, Bo = o["D"], o["DC"], o["N"], o["S"], o["B"]
+    x = T(gu.make_input("x", (Bo, No, Do), seed), dev, True)
+    ctx = T(gu.make_input("ctx", (Bo, So, DCo), seed), dev, True)
+    dy = T(gu.make_input("dy", (Bo, No, Do), seed), dev)
+    cmask = (torch.arange(So)[None, :] < torch.tensor([So, So - 9])[:, None]).to(dev)
+    blk = load_seeded(mods.TransformerBlock(Do, dim_heads=64, cross_attend=True, dim_context=DCo,
+                                            global_cond_dim=Do if ada else None, conformer=True), seed, dev)
+    rot = mods.RotaryEmbedding(32).to(dev)
+    kw = {}
+    if ada:
+        gc = T(gu.make_input("g", (Bo, Do), seed), dev, True)
+        kw["global_cond"] = gc
+    y = blk(x, context=ctx, context_mask=cmask, rotary_pos_emb=rot.forward_from_seq_len(No), **kw)
+    y.backward(dy)
+    assert rel(y, f[f"{tag}/y"]) < 1e-2, rel(y, f[f"{tag}/y"])
+    assert rel(x.grad, f[f"{tag}/dx"]) < 2e-2, rel(x.grad, f[f"{tag}/dx"])
+    assert rel(ctx.grad, f[f"{tag}/dctx"]) < 2e-2, rel(ctx.grad, f[f"{tag}/dctx"])
+    if ada:
+        assert rel(gc.grad, f[f"{tag}/dg"]) < 2e-2, rel(gc.grad, f[f"{tag}/dg"])
+    g = {n: p.grad for n, p in blk.named_parameters()}
+    assert all(v is not None and v.shape == p.shape for (n, p), v in zip(blk.named_parameters(), g.values()))
+    check_digests(f, g, 32, prefix=f"{tag}/")
+    for k in f.files:
+        if k.startswith(f"{tag}/grad/"):
+            name = k[len(tag) + 6:]
+            assert rel(g[name], f[k]) < 3e-2, (name, rel(g[name], f[k]))
+    xm = T(gu.make_input("xm", (Bo, No, Do), seed), dev, True)
+    ym = blk.conformer(xm)
+    ym.backward(dy)
+    assert rel(ym, f[f"{tag}/module_y"]) < 1e-2, rel(ym, f[f"{tag}/module_y"])
+    assert rel(xm.grad, f[f"{tag}/module_dx"]) < 2e-2, rel(xm.grad, f[f"{tag}/module_dx"])
+
+
+@pytest.mark.parametrize("tag,seed", [("ct_sin", 82), ("ct_abs", 83)])
+def test_continuous_transformer_position_embeddings(dev, tag, seed):
+    """ContinuousTransformer(use_sinusoidal_emb / use_abs_pos_emb) (transformer.py:45-87, 733-739, 796-797) against the reference:
+    output, input gradients, the embedding's own gradient in full (the learned scalar / the rows of the table that were used)"""
+    gu, T, fx, load_seeded, check_digests, mods = _opt_imports()
+    f = fx("block_options")
+    c = gu.OPT_CT
+    kw = dict(use_sinusoidal_emb=True) if tag == "ct_sin" else dict(use_abs_pos_emb=True, abs_pos_emb_max_length=c["max_len"])
+    ct = load_seeded(mods.ContinuousTransformer(dim=c["D"], depth=c["depth"], dim_in=c["dim_in"], dim_out=c["dim_out"],
+                                                dim_heads=64, **kw), seed, dev)
+    x = T(gu.make_input("x", (c["B"], c["N"], c["dim_in"]), seed), dev, True)
+    pe = T(gu.make_input("prepend", (c["B"], c["P"], c["D"]), seed), dev, True)
+    y = ct(x, prepend_embeds=pe)
+    y.backward(T(gu.make_input("dy", tuple(y.shape), seed), dev))
+    assert rel(y, f[f"{tag}/y"]) < 1e-2, rel(y, f[f"{tag}/y"])
+    assert rel(x.grad, f[f"{tag}/dx"]) < 2e-2, rel(x.grad, f[f"{tag}/dx"])
+    assert rel(pe.grad, f[f"{tag}/dprepend"]) < 2e-2, rel(pe.grad, f[f"{tag}/dprepend"])
+    g = {n: p.grad for n, p in ct.named_parameters()}
+    check_digests(f, g, 32, prefix=f"{tag}/")
+    for k in f.files:
+        if k.startswith(f"{tag}/grad/"):
+            name = k[len(tag) + 6:]
+            assert rel(g[name], f[k]) < 3e-2, (name, rel(g[name], f[k]))
+
+
+@pytest.mark.parametrize("S", [40, 48, 130])
+def test_transformer_block_causal_vs_oracle(dev, S):
+    """TransformerBlock(causal=True): self- and cross-attention under the mask of create_causal_mask (transformer.py:32-33; keys
+    c <= r + S - N).  Parity unpinned (the reference's causal calls raise, see Attention): held to the CPU oracle, which applies
+    that function's mask - S = N, S > N within one key block, and S = 130 (two key blocks behind 126 queries... here 40)."""
+    gu, T, fx, load_seeded, check_digests, mods = _opt_imports()
+    Do, DCo, No, Bo, seed = 256, 128, 40, 2, 91
+    x = T(gu.make_input("x", (Bo, No, Do), seed), dev, True)
+    ctx = T(gu.make_input("ctx", (Bo, S, DCo), seed), dev, True)
+    dy = T(gu.make_input("dy", (Bo, No, Do), seed), dev)
+    blk = load_seeded(mods.TransformerBlock(Do, dim_heads=64, cross_attend=True, dim_context=DCo, causal=True), seed, dev)
+    rot = mods.RotaryEmbedding(32).to(dev)
+    y = blk(x, context=ctx, rotary_pos_emb=rot.forward_from_seq_len(No))
+    y.backward(dy)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gu.make_state(
+        [(n, tuple(p.shape)) for n, p in blk.named_parameters()], seed).items()}
+    xr, cr = x.detach().cpu().requires_grad_(True), ctx.detach().cpu().requires_grad_(True)
+    yr = ko.transformer_block(sd, xr, context=cr, rotary=ko.rotary_freqs(No), causal=True)
+    yr.backward(dy.cpu())
+    # the mask matters: without it the output differs by far more than the tolerance
+    y_nc = ko.transformer_block({k: v.detach() for k, v in sd.items()}, xr.detach(), context=cr.detach(),
+                                rotary=ko.rotary_freqs(No), causal=False)
+    assert rel(y_nc, yr.detach()) > 5e-2
+    assert rel(y, yr.detach()) < 1e-2, rel(y, yr.detach())
+    assert rel(x.grad, xr.grad) < 2e-2, rel(x.grad, xr.grad)
+    assert rel(ctx.grad, cr.grad) < 2e-2, rel(ctx.grad, cr.grad)
+    for n, p in blk.named_parameters():
+        assert rel(p.grad, sd[n].grad) < 3e-2, (n, rel(p.grad, sd[n].grad))
+    # the stand-alone module, a single query: causal is switched off (transformer.py:468-469)
+    att = load_seeded(mods.Attention(Do, dim_heads=64, causal=True), seed + 1, dev)
+    x1 = T(gu.make_input("x1", (Bo, 1, Do), seed), dev)
+    sa = {k: torch.from_numpy(v) for k, v in gu.make_state([(n, tuple(p.shape)) for n, p in att.named_parameters()], seed + 1).items()}
+    assert rel(att(x1), ko.attention(sa, x1.cpu(), causal=True)) < 1e-2
+
+
+def test_conformer_dit_through_trainer_matches_autograd(dev):
+    """a DiT whose blocks carry a ConformerModule and a sinusoidal position embedding: the trainer path (matrix gradients of the
+    1 x 1 convolutions written into [N, K, 1] sinks by the grouped launch, the depthwise taps ADDED into a sink that is cleared
+    with the vectors) equals plain autograd on the same model over a window of two micro-batches, twice (stale sums would show in the second)"""
+    from kalle_audio_amd import engine
+    from kalle_audio_amd.stable_audio_tools.training.diffusion import diffusion_train_step
+    ref = _small_dit(dev, conformer=True, use_sinusoidal_emb=True)
+    lat, noise, t, cond = _batch(dev, 4, 5)
+    loss_ref, _ = diffusion_train_step(ref, lat, t, noise, cond, objective="v")
+    loss_ref.backward()
+    gref = {n: p.grad.clone() for n, p in ref.named_parameters()}
+    m = _small_dit(dev, conformer=True, use_sinusoidal_emb=True)
+    tr = engine.DataParallelTrainer(m, lr=0.0, optimizer="Adam", grad_accum_steps=2)
+    for i in range(2):      # two optimizer steps of two identical micro-batches each: mean of equal gradients = the gradient
+        for _ in range(2):
+            loss = tr.train_step(m, lat, t, noise, cond, objective="v")
+        torch.cuda.synchronize()
+        assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+        for n, _ in m.named_parameters():      # (the flat buffer holds the SUM over the window; 1 / accum is folded into Adam)
+            a, b = tr.flat.grad_view(n), 2.0 * gref[n]
+            assert rel(a, b) < 2e-3, (i, n, rel(a, b))
