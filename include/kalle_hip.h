@@ -98,6 +98,10 @@ int kalle_gemm_debug_stamps(void* buf);
  * staged, 2 computed, 3 stores issued, 4 stores acknowledged; fused self-attention backward: 0 entry, 1 tiles staged, 2 row
  * statistics ready, 3 dK / dV computed, 4 dK / dV stored, 5 dQ computed, 6 stores issued, 7 acknowledged */
 int kalle_attn_debug_stamps(void* buf);
+/* diagnostics (tools/cu_hold_probe.py), never called by the product path: `nwg` workgroups of 256 threads with `lds_bytes` of LDS
+ * each (<= 64 KiB) that do nothing but stay resident for `microseconds` - a stand-in for a communication kernel that holds some
+ * CUs while the GEMMs of the backward pass launch (a 160-KiB-LDS GEMM workgroup cannot share a CU with it) */
+int kalle_debug_hold_cus(int nwg, int lds_bytes, int microseconds, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (bias-less gamma, eps 1e-5) with optional adaLN modulation - one wavefront per row.

@@ -851,6 +851,42 @@ static int kalle_cu_count() {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FA[mt]),              \
                                                               __builtin_bit_cast(bf16x8, FB[nt]), acc[mt][nt], 0, 0, 0)
 
+// ---- dynamic tile hand-out of the persistent kernel ---------------------------------------------------------------------------
+// With a static walk (tiles b, b + grid, ...) a workgroup that starts late does its whole share late: when another kernel holds
+// some CUs while the GEMM launches - RCCL's all-reduce of the previous block's gradient bucket on the communication stream, the
+// optimizer slice on its side stream; neither can share a CU with a 160-KiB-LDS workgroup - the workgroups that found no CU run
+// after the others have finished (tools/cu_hold_probe.py: 16-64 CUs held -> 1.25-1.7 x the GEMM's time).  Instead every
+// workgroup takes tile b first and then DRAWS: counter x (one per XCD, each in its own 128-byte line, so that a workgroup keeps
+// walking the XCD-contiguous run of the raster whose panels its L2 holds) hands out ids x + 8 (grid / 8 + j) to the workgroups
+// of XCD x.  The draw is one returning atomic per tile by one lane and runs TWO
+// tiles ahead, because every K-tile of the main loop ends in s_waitcnt vmcnt(0) and would wait for it: it is issued at the start
+// of tile i's epilogue (for tile i + 2), right behind the requests for tile i + 1's first K-tiles, and its round trip runs under
+// the epilogue; at the start of tile i + 1 lane 0 leaves the id in wave 0's (idle) epilogue patch, the tile's first barrier
+// publishes it and every wave keeps it in an SGPR until the epilogue's hook asks which tile to prefetch.  Counter sets are self-cleaning: the
+// last workgroup to leave zeroes the set.
+constexpr int SCHED_SETS = 256;
+constexpr int SCHED_LINE = 32;                                   // ints per counter (one 128-byte line each)
+__device__ int kalle_gemm_sched[SCHED_SETS][9 * SCHED_LINE];     // [set]: 8 per-XCD counters, then the count of workgroups that left
+
+// the draw is split so that nothing waits for the atomic where it is issued: sched_issue returns the raw counter value (in
+// flight), sched_resolve - a tile later - turns it into a tile id.  There is no stealing across XCDs: a first version walked the
+// other XCDs' counters once a workgroup's own run was exhausted - every workgroup did that once per kernel, at the start of its
+// last tile, seven blocking round trips for nothing in the undisturbed case (+8 % on a 150-us GEMM) - and kernels that hold CUs
+// are spread over the XCDs by the dispatcher like everything else.
+__device__ __forceinline__ int sched_issue(int* sched, int xcd) { return atomicAdd(sched + xcd * SCHED_LINE, 1); }
+__device__ __forceinline__ int sched_resolve(int xcd, int raw, int first_round, int ntiles) {
+    const int id = xcd + 8 * (first_round + raw);
+    return id < ntiles ? id : ntiles;
+}
+__device__ __forceinline__ void sched_leave(int* sched, int nwg) {
+    // (no fence: every draw this workgroup issued has returned - its value was used - and the counters are only ever touched by
+    // device-scope atomics; an agent-scope release here would write back the XCD's L2, 256 times per kernel)
+    if (atomicAdd(sched + 8 * SCHED_LINE, 1) == nwg - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicExch(sched + i * SCHED_LINE, 0);
+    }
+}
+
 // 256 x 256 output tiles `tile0, tile0 + tstride, ...` (< tile_end; ids in the XCD-aware grouped raster, or plain raster for the
 // grouped launch) over K-tiles [kt0, kt0 + nk) of problem `p` - shared by the plain, the persistent and the grouped kernel.
 // PERSISTENT form (tstride > 0, one workgroup per CU walks its tiles): what the in-kernel stamps showed per K = 1536 tile - 1.6-2.4 us
@@ -902,11 +938,20 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
     bool prefetched = false;              // K-tiles 0 (and 1) of `tile` were requested by the previous tile's tail
     unsigned s0 = 0;                      // stage (byte offset) that holds K-tile 0 of `tile`
 
-    for (int tile = tile0; tile < tile_end; tile += tstride) {
+    // (the software-pipelined build variant keeps the static walk)
+    int* const sched = PERSIST && !KALLE_GEMM_PIPE && p.sched_set > 0 ? &kalle_gemm_sched[p.sched_set - 1][0] : nullptr;
+    int next_tile = tile_end;
+    int drawn = 0;                        // lane 0 of wave 0: the counter value drawn last (two tiles ahead of the one being computed)
+    if constexpr (PERSIST) {
+        if (sched && tid == 0) drawn = sched_issue(sched, blockIdx.x & 7);                             // the tile after the first
+    }
+    volatile int* const mailbox = reinterpret_cast<volatile int*>(smem + 2 * STAGE);   // wave 0's epilogue patch (idle in the main loop)
+    for (int tile = tile0; tile < tile_end; tile = next_tile) {
         int tm, tn;
         coords(tile, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
-        const bool has_next = PERSIST && tile + tstride < tile_end;
+        next_tile = PERSIST ? tile + tstride : tile_end;       // (dynamic hand-out: read from the mailbox behind the first barrier)
+        bool has_next = PERSIST && next_tile < tile_end;
         gemm_stamp(p, wave, lane, 0, tile);
         f32x4 acc[TM][4];
 #pragma unroll
@@ -930,8 +975,20 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
             init_loaders(tm, tn, nk > 1 ? 2 : 1);                  // (K-tiles 0 and 1 are on their way)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // both prefetched K-tiles + the previous epilogue's stores
         }
+        if constexpr (PERSIST) {
+            if (sched && tid == 0) {          // (the draw has returned: the waits above cover it)
+                *mailbox = sched_resolve(blockIdx.x & 7, drawn, tstride >> 3, tile_end);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PERSIST) {
+            if (sched) {
+                next_tile = __builtin_amdgcn_readfirstlane(*mailbox);
+                has_next = next_tile < tile_end;
+            }
+        }
         gemm_stamp(p, wave, lane, 1, tile);
 
 #if KALLE_GEMM_PIPE
@@ -1080,7 +1137,7 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
             if constexpr (!PERSIST) return;
             if (has_next) {
                 int ntm, ntn;
-                coords(tile + tstride, ntm, ntn);
+                coords(next_tile, ntm, ntn);
                 init_loaders(ntm, ntn, 0);
                 la.issue_at(smem + (s_last ^ STAGE), wave, lane, 0, tail_t, kvalid);
                 lb.issue_at(smem + (s_last ^ STAGE) + A_BYTES, wave, lane, 0, tail_t, kvalid);
@@ -1088,6 +1145,9 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
                     la.issue_at(smem + s_last, wave, lane, 1, tail_t, kvalid);
                     lb.issue_at(smem + s_last + A_BYTES, wave, lane, 1, tail_t, kvalid);
                 }
+                // the tile after the next one: the atomic's round trip runs under the epilogue (it is older than the epilogue's
+                // loads and stores, so nothing at the next tile's start waits for it)
+                if (sched && tid == 0) drawn = sched_issue(sched, blockIdx.x & 7);
             }
         };
         wave_epilogue<C_F32, TM, GLU>(p, acc, smem + 2 * STAGE, wave, lane, m0 + arow, GLU == 1 ? tn * 128 + wn * 32 : n0 + bcol,
@@ -1124,6 +1184,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(GemmParams p) {
         // whole-K tiles: gridDim.x <= tiles workgroups (one per CU) walk tiles b, b + grid, ...; a multiple-of-8 grid keeps a
         // workgroup's tiles on the XCD-contiguous run of the raster its XCD owns
         gemm3_tiles<A_KM, B_KM, C_F32, GLU, true, true>(p, blockIdx.x, gridDim.x, ntiles, ntiles, 0, nk_all);
+        if (!KALLE_GEMM_PIPE && p.sched_set > 0 && threadIdx.x == 0) sched_leave(&kalle_gemm_sched[p.sched_set - 1][0], gridDim.x);
     }
 }
 
@@ -1232,6 +1293,14 @@ int launch3(const GemmParams& p, hipStream_t st) {
                 if (!only_glu2 || GLU == 2) q.dephase_ticks = (int)(atof(only_glu2 ? de + 5 : de) * 100.0);
             }
             grid.x = cus;
+            // dynamic tile hand-out (KALLE_GEMM_DYNAMIC=0: static walk); a set is reused after SCHED_SETS persistent launches
+            static const bool dynamic = !(getenv("KALLE_GEMM_DYNAMIC") && atoi(getenv("KALLE_GEMM_DYNAMIC")) == 0);
+            static std::atomic<unsigned> next_set{0};
+            // (a launch that is being captured into a HIP graph keeps the static walk: a replayed node would come back with the
+            // same counter set while an eager launch on another stream may hold it)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+            q.sched_set = dynamic && !capturing ? 1 + (int)(next_set.fetch_add(1, std::memory_order_relaxed) % SCHED_SETS) : 0;
             KALLE_LAUNCH((gemm3_kernel<A_KM, B_KM, C_F32, GLU>), grid, block, lds, st, q);
             return kalle_check_launch();
         }
@@ -1633,6 +1702,20 @@ int kalle_gemm_few_rows_launch(const GemmParams& pin, bool a_km, bool b_km, bool
 
 static unsigned long long* g_stamps = nullptr;      // diagnostics only (kalle_gemm_debug_stamps)
 extern "C" int kalle_gemm_debug_stamps(void* buf) { g_stamps = static_cast<unsigned long long*>(buf); return KALLE_OK; }
+
+namespace {
+__global__ __launch_bounds__(256) void hold_cus_kernel(int ticks) {
+    extern __shared__ char hold_smem[];
+    if (ticks < 0) hold_smem[threadIdx.x] = 1;          // (keeps the allocation alive)
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)ticks;
+    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+extern "C" int kalle_debug_hold_cus(int nwg, int lds_bytes, int microseconds, void* stream) {
+    if (nwg <= 0 || nwg > 4096 || lds_bytes < 0 || lds_bytes > 65536 || microseconds < 0 || microseconds > 1000000) return KALLE_ERR_ARG;
+    KALLE_LAUNCH(hold_cus_kernel, dim3(nwg), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), microseconds * 100);
+    return kalle_check_launch();
+}
 
 static thread_local int g_last_plan = 0;
 extern "C" int kalle_gemm_last_plan(void) { return g_last_plan; }

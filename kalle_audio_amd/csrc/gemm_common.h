@@ -39,6 +39,9 @@ struct GemmParams {
     // persistent 256 x 256 kernel: every second group of 8 workgroups starts this many 10-ns ticks late, so that the CUs' epilogue
     // bursts (HBM-bound when all 256 fall together) interleave with the other half's main loops (0: lockstep)
     int dephase_ticks;
+    // persistent 256 x 256 kernel, dynamic tile hand-out: 0 = every workgroup walks tiles b, b + grid, ... (static); n >= 1 = after
+    // its first tile a workgroup draws the next one from counter set n - 1 (gemm2.hip, kalle_gemm_sched)
+    int sched_set;
     int dbg;        // knock-out timing of the fused SwiGLU backward epilogue (KALLE_GEMM_DBG): 1 = no h loads, 2 = no dh stores
 };
 
