@@ -1283,7 +1283,9 @@ int launch3(const GemmParams& p, hipStream_t st) {
         // (the same code with a grid of `tiles` workgroups: every workgroup finds no next tile)
         if (p.splits != 1) return KALLE_ERR_UNSUPPORTED;
         static const bool persist = !(getenv("KALLE_GEMM_PERSIST") && atoi(getenv("KALLE_GEMM_PERSIST")) == 0);
-        const int cus = kalle_cu_count();
+        // KALLE_GEMM_GRID: workgroups of the persistent launch (experiment: fewer than one per CU)
+        static const int grid_env = getenv("KALLE_GEMM_GRID") ? atoi(getenv("KALLE_GEMM_GRID")) & ~7 : 0;
+        const int cus = grid_env >= 8 ? std::min(grid_env, kalle_cu_count()) : kalle_cu_count();
         if (persist && (int)grid.x > cus) {
             // experiment switch: "us" for every shape, or "glu2:us" for the fused SwiGLU backward only
             static const char* de = getenv("KALLE_GEMM_DEPHASE_US");
