@@ -130,10 +130,14 @@ def _workspace(device, nbytes):
     """per (device, stream) scratch for kalle_gemm_bf16's few-rows path, grown on demand (never shrinks)"""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
-    if t is None or t.numel() < nbytes:
+    # (capped at 1 GiB - the kernel is told the size and splits K only as far as the scratch reaches.  The comparison must use
+    # the CAPPED size: comparing with the uncapped request re-allocated - and kept - a fresh GiB on every call once a shape asked
+    # for more than the cap, 4032 rows x 12288 columns at B = 32 per GPU: 11 GB per step until the device was full)
+    need = max(min(nbytes, 1 << 30), 64 << 20)
+    if t is None or t.numel() < need:
         if t is not None:
             _WS_KEEP.append(t)          # a captured HIP graph may still point at the old scratch: never hand it back
-        t = _WS[key] = torch.empty(max(min(nbytes, 1 << 30), 64 << 20), device=device, dtype=torch.uint8)
+        t = _WS[key] = torch.empty(need, device=device, dtype=torch.uint8)
     return t
 
 

@@ -282,3 +282,34 @@ def test_shim_pythonpath_needs_no_edited_line(tmp_path):
     r = subprocess.run([sys.executable, "train.py"], cwd=tmp_path, capture_output=True, text=True, timeout=300,
                        env=dict(env, KALLE_SHIM="0"))
     assert r.returncode != 0 and "the reference module was imported" in r.stderr      # switched off: the directory wins again
+
+
+def test_gemm_workspace_is_capped_and_reused(monkeypatch):
+    """ops._workspace: a request beyond the 1 GiB cap must be served by ONE capped buffer that later calls reuse (round 3: it was
+    re-allocated - and the old one kept - on every call, 11 GB per train step at 32 clips per GPU)"""
+    from kalle_audio_amd import ops
+    made = []
+
+    class _Stream:
+        cuda_stream = 7
+
+    monkeypatch.setattr(ops.torch.cuda, "current_stream", lambda device=None: _Stream())
+    monkeypatch.setattr(ops.torch, "empty", lambda n, device=None, dtype=None: _Fake(n, made))
+    monkeypatch.setattr(ops, "_WS", {})
+    monkeypatch.setattr(ops, "_WS_KEEP", [])
+    dev = torch.device("cuda", 0)
+    a = ops._workspace(dev, 4 * 4032 * 12288 * 8)          # 1.58 GB asked
+    b = ops._workspace(dev, 4 * 4032 * 12288 * 8)
+    c = ops._workspace(dev, 1 << 20)
+    assert a is b is c and made == [1 << 30] and ops._WS_KEEP == []
+    d = ops._workspace(torch.device("cuda", 1), 1 << 20)
+    assert d is not a and made == [1 << 30, 64 << 20]
+
+
+class _Fake:
+    def __init__(self, n, log):
+        self.n = n
+        log.append(n)
+
+    def numel(self):
+        return self.n
