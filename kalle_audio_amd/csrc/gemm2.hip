@@ -926,6 +926,9 @@ __device__ __forceinline__ void gemm3_tiles(const GemmParams& p, int tile0, int 
         else gemm_tile_coords_plain(tile, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     };
     auto init_loaders = [&](int tm, int tn, int kt_first) {      // source pointers of K-tile `kt_first` of this workgroup's range
+        // (KALLE_GEMM_DBG bit 2, timing experiment only - results are wrong: every workgroup fetches the operand panels of tile
+        // (tm & 1, tn & 1), i.e. all of an XCD's workgroups share four panels and the L2 -> LDS stream runs at ~100 % L2 hits)
+        if (p.dbg & 4) { tm &= 1; tn &= 1; }
         la.init(p.A, p.lda, p.M, tm * BM, (kt0 + kt_first) * BK2, wave, lane);
         lb.init(p.B, p.ldb, p.N, tn * BN, (kt0 + kt_first) * BK2, wave, lane, GLU == 1 ? p.glu_inner : 0, tn);
     };
