@@ -587,3 +587,42 @@ def test_batch_size_sweep_full_width(dev):
         step(B)
         torch.cuda.empty_cache()
         assert torch.cuda.memory_allocated() <= m0 + (8 << 20), (B, m0, torch.cuda.memory_allocated())
+
+
+def test_dynamic_tile_handout_is_exact_under_contention_and_across_streams(dev):
+    """the persistent 256 x 256 kernel draws its tiles from per-XCD counters (gemm2.hip, kalle_gemm_sched): every tile is computed
+    exactly once whatever the order - results are BIT-identical (a) run to run, (b) with a kernel holding 48 CUs while the GEMM
+    launches (kalle_debug_hold_cus: workgroups start late and the others take over their tiles), (c) with two persistent GEMMs
+    of different shapes in flight on two streams (each launch owns its counter set), and the sets clean themselves (300
+    launches reuse every one of the 256 sets)"""
+    import ctypes
+    from kalle_audio_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(3)
+    mk = lambda r, c: (torch.randn(r, c, generator=g, device=dev) * 0.5).bfloat16()
+    a1, b1 = mk(16100, 1536), mk(4608, 1536)         # 63 x 18 = 1134 tiles of 256 x 256 (ragged last row tile)
+    a2, b2 = mk(32256, 1536), mk(1536, 1536)         # k-major B: 126 x 6 = 756 tiles (a shape of the train step)
+    ref1 = ops.gemm(a1, b1)
+    assert (lib.kalle_gemm_last_plan() & 255) == 3, lib.kalle_gemm_last_plan()
+    ref2 = ops.gemm(a2, b2, b_kmajor=True)
+    assert (lib.kalle_gemm_last_plan() & 255) == 3, lib.kalle_gemm_last_plan()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a1, b1), ref1)
+    side = torch.cuda.Stream()
+    for held in (16, 48, 96):
+        with torch.cuda.stream(side):
+            assert lib.kalle_debug_hold_cus(held, 16384, 1500, ctypes.c_void_p(side.cuda_stream)) == 0
+        out = ops.gemm(a1, b1)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref1), held
+    outs = []
+    for i in range(150):
+        with torch.cuda.stream(side):
+            o2 = ops.gemm(a2, b2, b_kmajor=True)
+        o1 = ops.gemm(a1, b1)
+        if i % 50 == 49:
+            outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
