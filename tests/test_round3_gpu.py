@@ -626,3 +626,66 @@ def test_dynamic_tile_handout_is_exact_under_contention_and_across_streams(dev):
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+
+
+# ------------------------------------------------------------------------------------------------ configuration fuzz
+def _fuzz_cases():
+    import random
+    rnd = random.Random(20261004)
+    cases = []
+    for i in range(16):
+        heads = rnd.choice([2, 3, 4, 5, 6])
+        kv = rnd.choice([k for k in (1, 2, 3, 4, 5) if heads % k == 0])     # (transformer.py:505-508: heads // kv_heads query heads per kv head)
+        cases.append(dict(seed=300 + i, D=64 * heads, heads=heads, depth=rnd.choice([1, 2, 3]), cio=rnd.choice([8, 16, 40, 64]),
+                          dc=64 * kv, gd=rnd.choice([16, 32, 96]), gtype=rnd.choice(["prepend", "adaLN"]),
+                          T=rnd.choice([7, 33, 64, 125, 130, 257]), S=rnd.choice([1, 7, 77, 130, 145, 200]),
+                          B=rnd.choice([1, 2, 3, 5]), obj=rnd.choice(["v", "rectified_flow"]), proj=rnd.choice([True, False]),
+                          pad=rnd.choice([True, False]), cmask=rnd.choice([True, False])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=lambda c: f"s{c['seed']}-D{c['D']}-L{c['depth']}-T{c['T']}-S{c['S']}-B{c['B']}-{c['gtype']}")
+def test_dit_train_step_configuration_fuzz(dev, c):
+    """seeded random DiT configurations - widths of 2-5 heads, 1-3 blocks, odd latent / context lengths (7 ... 257 frames, 1 ... 200
+    context tokens: ragged K-tiles, one to three key blocks, the folded key tail), batch 1-5, both global-conditioning types, both
+    objectives, with / without conditioning projection, padding mask and context mask - one train step (loss, output, EVERY
+    parameter gradient) against the CPU oracle on the same weights.  Tolerances of a 1-3 block bf16 path: loss 1e-2, output rel-L2
+    2e-2 (cosine 0.999), gradients 4e-2 of the tensor's norm (tiny tensors: of the largest gradient norm in the model)."""
+    import golden_util as gu
+    from test_modules_gpu import load_seeded
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    from kalle_audio_amd import functional as KF, ops
+    seed = c["seed"]
+    dit = load_seeded(DiffusionTransformer(io_channels=c["cio"], embed_dim=c["D"], depth=c["depth"], num_heads=c["heads"],
+                                           cond_token_dim=c["dc"], project_cond_tokens=c["proj"], global_cond_dim=c["gd"],
+                                           transformer_type="continuous_transformer", global_cond_type=c["gtype"]), seed, dev)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in gu.make_state(
+        [(n, tuple(p.shape)) for n, p in dit.named_parameters()], seed).items()}
+    B, T, S = c["B"], c["T"], c["S"]
+    lat = torch.from_numpy(gu.make_input("lat", (B, c["cio"], T), seed))
+    noise = torch.from_numpy(gu.make_input("noise", (B, c["cio"], T), seed))
+    t = torch.linspace(0.08, 0.93, B)
+    ctx = torch.from_numpy(gu.make_input("ctx", (B, S, c["dc"]), seed))
+    gl = torch.from_numpy(gu.make_input("glob", (B, c["gd"]), seed))
+    pm = torch.from_numpy(gu.make_mask("pm", (B, T), seed, 0.8)) if c["pad"] else None
+    cm = torch.from_numpy(gu.make_mask("cm", (B, S), seed, 0.7)) if c["cmask"] else None
+    ocfg = dict(embed_dim=c["D"], depth=c["depth"], num_heads=c["heads"], global_cond_type=c["gtype"])
+    loss_ref, out_ref, _, _ = ko.train_step_loss(sd, ocfg, lat, noise, t, c["obj"], padding_mask=pm, cross_attn_cond=ctx,
+                                                 cross_attn_cond_mask=cm, global_embed=gl)
+    loss_ref.backward()
+    xt, tgt = ops.diffuse_fwd(lat.to(dev), noise.to(dev), t.to(dev), c["obj"])
+    out = dit(xt, t.to(dev), cross_attn_cond=ctx.to(dev), cross_attn_cond_mask=None if cm is None else cm.to(dev),
+              global_embed=gl.to(dev), cfg_dropout_prob=0.0)
+    loss = KF.MSELossFn.apply(out, tgt, None if pm is None else pm.to(dev), 1.0)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    assert cosine(out, out_ref.detach()) > 0.999 and rel(out, out_ref.detach()) < 2e-2, rel(out, out_ref.detach())
+    gmax = max(v.grad.norm().item() for v in sd.values() if v.grad is not None)
+    for n, p in dit.named_parameters():
+        g_ref = sd[n].grad
+        if g_ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, n
+            continue
+        assert p.grad is not None, n
+        err = (p.grad.float().cpu() - g_ref).norm().item()
+        assert err <= 4e-2 * max(g_ref.norm().item(), 2e-2 * gmax), (n, err, g_ref.norm().item(), gmax)
