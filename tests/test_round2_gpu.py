@@ -482,8 +482,9 @@ def _small_dit(dev, seed=70, depth=2, **kw):
     import kalle_audio_amd
     kalle_audio_amd.install()
     from stable_audio_tools.models.diffusion import ConditionedDiffusionModelWrapper, DiTWrapper
+    kw.setdefault("global_cond_type", "prepend")
     dit = DiTWrapper(io_channels=CIO, embed_dim=D, depth=depth, num_heads=2, cond_token_dim=DC, project_cond_tokens=False,
-                     global_cond_dim=GD, transformer_type="continuous_transformer", global_cond_type="prepend", **kw)
+                     global_cond_dim=GD, transformer_type="continuous_transformer", **kw)
     load_seeded(dit, seed, dev)
     return ConditionedDiffusionModelWrapper(dit, None, io_channels=CIO, sample_rate=16000, min_input_length=1,
                                             cross_attn_cond_ids=["prompt"], global_cond_ids=["g"]).to(dev)
