@@ -739,3 +739,49 @@ def test_generation_graph_replay_fuzz(dev, monkeypatch, B, T_, S, cfg_scale, obj
     for a, b in zip(outs["1"], outs["0"]):
         assert torch.isfinite(a).all() and torch.equal(a, b), rel(a, b)
     assert torch.equal(outs["1"][0], outs["1"][2]) and not torch.equal(outs["1"][0], outs["1"][1])
+
+
+def _vae_fuzz_cases():
+    import random
+    rnd = random.Random(77)
+    cases = []
+    for i in range(8):
+        nlev = rnd.choice([2, 3, 4])
+        strides = [rnd.choice([2, 3, 4, 5, 8]) for _ in range(nlev)]
+        cases.append(dict(seed=400 + i, ch=rnd.choice([4, 8, 12, 16]), c_mults=[1, 2, 4, 8][:nlev], strides=strides,
+                          lat=rnd.choice([2, 4, 6, 8]), snake=rnd.choice([True, False]), audio=rnd.choice([1, 2]),
+                          B=rnd.choice([1, 2, 3]), frames=rnd.choice([5, 17, 40, 63])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _vae_fuzz_cases(), ids=lambda c: f"s{c['seed']}-ch{c['ch']}-{'x'.join(map(str, c['strides']))}-B{c['B']}-f{c['frames']}")
+def test_oobleck_vae_configuration_fuzz(dev, c):
+    """seeded random Oobleck autoencoders - 2-4 levels, strides 2-8 in any order, 4-16 base channels (so widths the conv kernels'
+    8- and 16-channel wave tiles do not divide), mono / stereo, SnakeBeta / ELU, 5-63 latent frames, batch 1-3 - encode and decode
+    against the CPU oracle on the same weights (fp32 conv path: rel-L2 1e-4)."""
+    import golden_util as gu
+    from test_modules_gpu import load_seeded
+    from stable_audio_tools.models.factory import create_model_from_config
+    ratio = 1
+    for s_ in c["strides"]:
+        ratio *= s_
+    cfg = {"model_type": "autoencoder", "sample_rate": 16000, "sample_size": ratio * c["frames"], "audio_channels": c["audio"],
+           "model": {"encoder": {"type": "oobleck", "config": {"in_channels": c["audio"], "channels": c["ch"], "c_mults": c["c_mults"],
+                                                              "strides": c["strides"], "latent_dim": 2 * c["lat"],
+                                                              "use_snake": c["snake"]}},
+                     "decoder": {"type": "oobleck", "config": {"out_channels": c["audio"], "channels": c["ch"], "c_mults": c["c_mults"],
+                                                              "strides": c["strides"], "latent_dim": c["lat"], "use_snake": c["snake"],
+                                                              "final_tanh": c["snake"]}},
+                     "bottleneck": {"type": "vae"}, "latent_dim": c["lat"], "downsampling_ratio": ratio, "io_channels": c["audio"]}}
+    ae = load_seeded(create_model_from_config(cfg), c["seed"], dev)
+    ae.eval().requires_grad_(False)
+    sd = {k: torch.from_numpy(v) for k, v in gu.make_state([(n, tuple(p.shape)) for n, p in ae.named_parameters()], c["seed"]).items()}
+    wav = torch.from_numpy(gu.make_input("wav", (c["B"], c["audio"], ratio * c["frames"]), c["seed"], 0.5))
+    with torch.no_grad():
+        z_ref = ko.oobleck_encoder(ko._sub(sd, "encoder."), wav, c["strides"], c["snake"])
+        z = ae.encode(wav.to(dev))
+        assert z.shape == z_ref.shape and rel(z, z_ref) < 1e-4, (tuple(z.shape), tuple(z_ref.shape), rel(z, z_ref))
+        zl = z_ref[:, :c["lat"]].contiguous()
+        rec_ref = ko.oobleck_decoder(ko._sub(sd, "decoder."), zl, c["strides"], c["snake"], final_tanh=c["snake"])
+        rec = ae.decode(zl.to(dev))
+        assert rec.shape == rec_ref.shape and rel(rec, rec_ref) < 1e-4, (tuple(rec.shape), rel(rec, rec_ref))
