@@ -132,6 +132,14 @@ int kalle_layernorm_bwd_acc(const void* dy, const void* x, int x_dtype, const fl
                             const float* mean, const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
                             float* dgamma_acc, float* dbeta_acc, int rows, int D, void* stream);
 
+/* the _acc form with the COLUMN SUMS of the bf16-rounded dx added atomically into dx_colsum_acc [D] (fp32) in place of dbeta:
+ * dx of a block's pre_norm is the output gradient of the block below, whose FF-out bias gradient (transformer.py:252,
+ * nn.Linear(inner, dim) with bias) is exactly that sum - fused here it saves a pass over the [rows][D] bf16 gradient */
+int kalle_layernorm_bwd_colsum(const void* dy, const void* x, int x_dtype, const float* gamma,
+                               const float* scale, int64_t ld_mod, int rows_per_batch,
+                               const float* mean, const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
+                               float* dgamma_acc, float* dx_colsum_acc, int rows, int D, void* stream);
+
 /* adaLN modulation gradients: dscale[b,d] = sum_t dy*ln, dshift[b,d] = sum_t dy   (transformer.py:665,679) */
 int kalle_adaln_mod_bwd(const void* dy, const void* x, int x_dtype, const float* gamma, const float* beta,
                         const float* mean, const float* rstd, float* dscale, float* dshift, int64_t ld_mod,

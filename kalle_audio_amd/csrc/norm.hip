@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ rstd, const float* dres, float* dx,
                                                      bf16_t* __restrict__ dxb,
                                                      float* __restrict__ dgp, float* __restrict__ dbp, int rows, int D,
-                                                     int atomic) {
+                                                     int atomic, int ab_mode) {
+    // ab_mode 0: the second accumulator is dbeta = sum_rows dy; 1: the column sums of the bf16-rounded dx (the bias gradient of
+    // the Linear whose output gradient this dx is - the FF-out bias of the block below - fused here instead of a pass over dxb)
     __shared__ float red[4][64 * 8 + 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NCH][8], ab[NCH][8], g[NCH][8];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 for (int e = 0; e < 8; ++e) {
                     xh[j][e] = (xv[e] - mu) * rs;
                     ag[j][e] += d[e] * xh[j][e];
-                    ab[j][e] += d[e];
+                    if (ab_mode == 0) ab[j][e] += d[e];
                     dh[j][e] = d[e] * g[j][e];
                     c1 += dh[j][e];
                     c2 += dh[j][e] * xh[j][e];
@@ -172,6 +174,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 }
                 store8<true>(dx, (int64_t)row * D + col, o);
                 if (dxb) store8<false>(dxb, (int64_t)row * D + col, o);
+                if (ab_mode == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ab[j][e] += bf16_to_f32(f32_to_bf16(o[e]));
+                }
             }
         }
     }
@@ -528,7 +534,7 @@ extern "C" int kalle_layernorm_bwd_parts(int rows) {
 static int ln_bwd_launch(const void* dy, const void* x, int x_dtype, const float* gamma, const float* scale,
                          int64_t ld_mod, int rows_per_batch, const float* mean, const float* rstd, const float* dres,
                          float* dx_out, void* dx_bf16, float* dgamma_part, float* dbeta_part, int rows, int D, int atomic,
-                         void* stream);
+                         void* stream, int ab_mode = 0);
 
 extern "C" int kalle_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* gamma,
                                    const float* scale, int64_t ld_mod, int rows_per_batch, const float* mean,
@@ -547,10 +553,19 @@ extern "C" int kalle_layernorm_bwd_acc(const void* dy, const void* x, int x_dtyp
                          dgamma_acc, dbeta_acc, rows, D, 1, stream);
 }
 
+extern "C" int kalle_layernorm_bwd_colsum(const void* dy, const void* x, int x_dtype, const float* gamma,
+                                          const float* scale, int64_t ld_mod, int rows_per_batch, const float* mean,
+                                          const float* rstd, const float* dres, float* dx_out, void* dx_bf16,
+                                          float* dgamma_acc, float* dx_colsum_acc, int rows, int D, void* stream) {
+    if (!dx_colsum_acc) return KALLE_ERR_ARG;
+    return ln_bwd_launch(dy, x, x_dtype, gamma, scale, ld_mod, rows_per_batch, mean, rstd, dres, dx_out, dx_bf16,
+                         dgamma_acc, dx_colsum_acc, rows, D, 1, stream, 1);
+}
+
 static int ln_bwd_launch(const void* dy, const void* x, int x_dtype, const float* gamma, const float* scale,
                          int64_t ld_mod, int rows_per_batch, const float* mean, const float* rstd, const float* dres,
                          float* dx_out, void* dx_bf16, float* dgamma_part, float* dbeta_part, int rows, int D, int atomic,
-                         void* stream) {
+                         void* stream, int ab_mode) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx_out || rows <= 0 || (D & 7) || D <= 0 || D > 4096)
         return KALLE_ERR_ARG;
     const int rpb = rows_per_batch > 0 ? rows_per_batch : 1;
@@ -560,11 +575,11 @@ static int ln_bwd_launch(const void* dy, const void* x, int x_dtype, const float
     if (x_dtype == KALLE_F32)                                                                                     \
         KALLE_LAUNCH((ln_bwd_kernel<N, true>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x, gamma, \
                            scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16), dgamma_part,   \
-                           dbeta_part, rows, D, atomic);                                                           \
+                           dbeta_part, rows, D, atomic, ab_mode);                                                  \
     else                                                                                                          \
         KALLE_LAUNCH((ln_bwd_kernel<N, false>), grid, block, 0, st, static_cast<const bf16_t*>(dy), x,      \
                            gamma, scale, ld_mod, rpb, mean, rstd, dres, dx_out, static_cast<bf16_t*>(dx_bf16),         \
-                           dgamma_part, dbeta_part, rows, D, atomic);
+                           dgamma_part, dbeta_part, rows, D, atomic, ab_mode);
     DISPATCH_NCH(D, CALL);
 #undef CALL
     return kalle_check_launch();

@@ -68,6 +68,7 @@ class GradOut:
         self.deferred = None            # list of (name, dy, x) while a block's weight gradients are being collected
         self.wgrad_overwrite = False    # trainer, first micro-batch: weight-gradient sinks are NOT pre-cleared - write, don't add
         self.touched = set()            # sink names some kernel of this backward pass has written (or added into)
+        self.colsum_fused = False       # the last ln() call added the column sums of its dx into the sink it was handed
 
     def _sink(self, name):
         s = self.sinks.get(self.prefix + name)
@@ -156,6 +157,10 @@ class GradOut:
     def ln(self, name, dy, x, gamma, mean, rstd, want_bf16=False, **kw):
         """LayerNorm backward: returns (dx fp32, dx bf16 | None); dgamma goes to the sink / grads."""
         s = self._sink(name)
+        if kw.get("dx_colsum_out") is not None and not (s is not None and self.accumulate and want_bf16
+                                                        and _os.environ.get("KALLE_LN_ATOMIC", "1") != "0"):
+            kw = dict(kw, dx_colsum_out=None)       # (only the atomic trainer path carries the fused column sums)
+        self.colsum_fused = kw.get("dx_colsum_out") is not None
         dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
         dx, dgamma, _ = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma_out=s.view(-1) if s is not None else None,
                                           accumulate=self.accumulate if s is not None else False, dx_bf16=dxb, **kw)
@@ -380,10 +385,15 @@ def ff_fwd(h, w1, b1, w2, b2, N, residual=None, gate=None, out_dtype=F32):
     return out, (hf, act)
 
 
-def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff."):
+def ff_bwd(go, gb, h, saved, w1, w2, want_bias=True, pre="ff.ff.", bias2_done=False):
+    """bias2_done: the column sums of gb are already in the FF-out bias sink (added by the LayerNorm backward that produced gb,
+    kalle_layernorm_bwd_colsum)"""
     hf, act = saved
     go.wgrad(pre + "2.weight", gb, act)
-    if want_bias:
+    if want_bias and bias2_done:
+        go._sink(pre + "2.bias")
+        go.grads[pre + "2.bias"] = None
+    elif want_bias:
         go.colsum(pre + "2.bias", gb)
     db1 = go.bias_acc(pre + "0.proj.bias", hf.shape[-1], hf.device) if want_bias else None
     dhf = torch.empty_like(hf)
@@ -546,7 +556,7 @@ def block_fwd(p, x, ctx, global_cond, mask8, cmask8, rope, B, N, S, ckv=None):
 
 
 def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=None, want_dctx=True, g_bf16=None,
-              want_dx_bf16=False):
+              want_dx_bf16=False, bias2_done=False, dx_colsum_out=None):
     """g: fp32 [B*N, D] gradient of the block output (g_bf16: the same values already rounded to bf16, when the
     producer - the next block's LayerNorm backward - emitted them).  Returns (dx fp32, dctx fp32|None,
     dglobal fp32|None, go, dx bf16|None)."""
@@ -565,7 +575,8 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         dsl(5).copy_(dg)
     else:
         gb = g_bf16 if g_bf16 is not None else ops.cast(g, BF16)
-    dh3 = ff_bwd(go, gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None)
+    dh3 = ff_bwd(go, gb, sv.h3, sv.ff, p.w1, p.w2, want_bias=p.b1 is not None,
+                 bias2_done=bias2_done and g_bf16 is not None and not ada)
     if ada:
         dsc, dsh = ops.adaln_mod_bwd(dh3, xin_ff, p.g3, p.beta3, sv.mean3, sv.rstd3, B, N)
         dsl(3).copy_(dsc)
@@ -597,8 +608,10 @@ def block_bwd(p, sv, g, ctx, mask8, cmask8, rope, B, N, S, go=None, dctx_acc=Non
         dsc, dsh = ops.adaln_mod_bwd(dh1, sv.x, p.g1, p.beta1, sv.mean1, sv.rstd1, B, N)
         dsl(0).copy_(dsc)
         dsl(1).copy_(dsh)
+    # (dx_colsum_out: the FF-out bias sink of the block BELOW - its output gradient is this dx - fused into this pass)
     dx, dxb = go.ln("pre_norm.gamma", dh1, sv.x, p.g1, sv.mean1, sv.rstd1, scale=sl(0), rows_per_batch=N, dres=g1,
-                    want_bf16=want_dx_bf16)
+                    want_bf16=want_dx_bf16, dx_colsum_out=dx_colsum_out if want_dx_bf16 else None)
+    go.dx_colsum_fused = go.colsum_fused
     dglobal = None
     if ada:
         dmb = ops.cast(dmod, BF16)

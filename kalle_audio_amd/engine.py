@@ -228,6 +228,12 @@ class DataParallelTrainer:
             blk._kalle_grad_accumulate = False
             blk._kalle_bucket_key = pre
             blk._kalle_on_backward_done = self._on_block_done
+        # consecutive blocks of one transformer know each other: the LayerNorm backward that produces a block's output gradient
+        # also adds its column sums into that block's FF-out bias sink (functional.TransformerBlockFn.backward)
+        for (na, a), (nb, b_) in zip(self.blocks, self.blocks[1:]):
+            if (isinstance(a, TransformerBlock) and isinstance(b_, TransformerBlock) and na.rsplit(".", 1)[0] == nb.rsplit(".", 1)[0]
+                    and getattr(b_, "layer_ix", -1) == getattr(a, "layer_ix", -9) + 1):
+                object.__setattr__(b_, "_kalle_prev_block", a)      # (not a child module: plain attribute)
         # large tables whose backward scatter-adds straight into the flat gradient (token embeddings)
         for n, p in named:
             if getattr(p, "_kalle_wants_sink", False) and bucket_of(n) == "_rest":

@@ -2,6 +2,8 @@
 reference training loop (plain torch autograd, any torch optimizer) runs the hand-written HIP kernels end to end.
 No torch math op computes anything here; torch supplies tensors, streams and the autograd tape only.
 """
+import os
+
 import torch
 
 from . import dit_ops as D
@@ -373,8 +375,19 @@ class TransformerBlockFn(torch.autograd.Function):
         # bf16 copy of the incoming gradient, if the block above (layer_ix + 1) left one for exactly this tensor
         sh = _GRAD_SHADOW.pop(gf.data_ptr(), None)
         g_bf16 = None
+        bias2_done = False
         if sh is not None and sh[0] == blk.layer_ix + 1 and sh[1].shape == gf.shape:
             g_bf16 = sh[1]
+            bias2_done = len(sh) > 3 and sh[3]
+        pend = getattr(blk, "_kalle_colsum_pending", None)
+        if pend is not None:
+            blk._kalle_colsum_pending = None
+            if not bias2_done or pend[0] != gf.data_ptr():
+                # the block above fused the column sums of ITS dx into this block's FF-out bias sink, but this block's output
+                # had a second consumer (the gradient that arrived is their sum, another tensor): take that contribution out
+                # again - the column-sum pass below covers the whole gradient
+                pend[1].sub_(ops.colsum(pend[2]))
+                bias2_done = False
         if len(_GRAD_SHADOW) > 8:
             _GRAD_SHADOW.clear()
         # The context feeds every layer: instead of 24 fp32 gradients that autograd adds up one by one, the first backward
@@ -382,9 +395,19 @@ class TransformerBlockFn(torch.autograd.Function):
         # return None (the producer of the context runs its backward only after every layer has contributed).
         dst = ctx.dctx_state if (ctx.needs_input_grad[2] and ctx.dtypes[1] == F32) else None
         acc = dst.get("acc") if dst is not None else None
+        # the FF-out bias sink of the block below, if the trainer linked the blocks and its sinks take atomic adds this step
+        prev = getattr(blk, "_kalle_prev_block", None)
+        cs = None
+        if (sinks and prev is not None and getattr(prev, "_kalle_grad_accumulate", False)
+                and getattr(blk, "_kalle_grad_accumulate", False) and os.environ.get("KALLE_FUSE_BIAS_COLSUM", "1") != "0"):
+            cs = (getattr(prev, "_kalle_grad_sinks", None) or {}).get("ff.ff.2.bias")
+            if cs is not None and getattr(prev, "global_cond_dim", None):
+                cs = None               # (adaLN blocks form their bf16 output gradient in grad_cast, not from this dx)
         dx, dctx, dglobal, go, dxb = D.block_bwd(p, sv, gf, ctx.ctxb, mask8, cmask8, rope, B, N, S, go=go,
                                                  want_dctx=ctx.needs_input_grad[2], g_bf16=g_bf16,
-                                                 want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx), dctx_acc=acc)
+                                                 want_dx_bf16=blk.layer_ix > 0 and xdt_is_f32(ctx), dctx_acc=acc,
+                                                 bias2_done=bias2_done, dx_colsum_out=cs.view(-1) if cs is not None else None)
+        fused = cs is not None and getattr(go, "dx_colsum_fused", False)
         if dst is not None and dctx is not None:
             if acc is None:
                 dst["acc"] = dctx                     # first contribution: this tensor is the gradient
@@ -398,7 +421,9 @@ class TransformerBlockFn(torch.autograd.Function):
         xdt, cdt, gdt = ctx.dtypes
         dx = _like(dx, xdt if xdt in (F32, BF16) else F32).view(B, N, Dm)
         if dxb is not None:
-            _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb, dx)
+            _GRAD_SHADOW[dx.data_ptr()] = (blk.layer_ix, dxb, dx, fused)
+            if fused:
+                prev._kalle_colsum_pending = (dx.data_ptr(), cs.view(-1), dxb)
         if dctx is not None and ctx.needs_input_grad[2]:
             dctx = dctx.view(ctx.ctx_shape).to(cdt)
         else:

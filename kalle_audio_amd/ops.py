@@ -161,15 +161,22 @@ def layernorm_fwd(x, gamma, beta=None, scale=None, shift=None, rows_per_batch=0,
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, scale=None, rows_per_batch=0, dres=None, dx_out=None, want_dbeta=False,
-                  dgamma_out=None, accumulate=False, dx_bf16=None):
+                  dgamma_out=None, accumulate=False, dx_bf16=None, dx_colsum_out=None):
     """returns (dx fp32, dgamma fp32 [D], dbeta fp32 [D] or None); dgamma_out (+accumulate) writes dgamma in place;
-    dx_bf16: optional bf16 tensor that receives a rounded copy of dx"""
+    dx_bf16: optional bf16 tensor that receives a rounded copy of dx; dx_colsum_out (trainer mode only: dgamma_out +
+    accumulate): fp32 [D] that the kernel atomically ADDS the column sums of the bf16-rounded dx to"""
     lib = _lib.load()
     rows, D = _rows2d(x)
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
     if dx_out is None:
         dx_out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     ld_mod = scale.stride(-2) if scale is not None else 0
+    if dx_colsum_out is not None:
+        assert dgamma_out is not None and accumulate and not want_dbeta
+        check(lib.kalle_layernorm_bwd_colsum(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),
+                                             _p(rstd), _p(dres), _p(dx_out), _p(dx_bf16), _p(dgamma_out), _p(dx_colsum_out),
+                                             rows, D, _stream()), "kalle_layernorm_bwd_colsum")
+        return dx_out, dgamma_out, None
     if dgamma_out is not None and accumulate and not want_dbeta and os.environ.get("KALLE_LN_ATOMIC", "1") != "0":
         # trainer mode: the gradient sink already holds this step's running sum - add into it from the kernel
         check(lib.kalle_layernorm_bwd_acc(_p(dy), _p(x), _dt(x), _p(gamma), _p(scale), ld_mod, rows_per_batch, _p(mean),

@@ -785,3 +785,44 @@ def test_oobleck_vae_configuration_fuzz(dev, c):
         rec_ref = ko.oobleck_decoder(ko._sub(sd, "decoder."), zl, c["strides"], c["snake"], final_tanh=c["snake"])
         rec = ae.decode(zl.to(dev))
         assert rec.shape == rec_ref.shape and rel(rec, rec_ref) < 1e-4, (tuple(rec.shape), rel(rec, rec_ref))
+
+
+def test_fused_bias_column_sums_and_second_consumers(dev, monkeypatch):
+    """trainer mode: the LayerNorm backward that produces a block's output gradient also adds its column sums into that block's
+    FF-out bias sink (kalle_layernorm_bwd_colsum).  (a) the flat gradient equals the un-fused path's; (b) when a block's output
+    has a SECOND consumer (hidden states in the loss) the gradient that reaches the block is another tensor - the fused
+    contribution is taken out again and the bias gradient is still that of plain autograd"""
+    import golden_util as gu
+    from test_modules_gpu import load_seeded
+    from kalle_audio_amd import engine
+    from stable_audio_tools.models import transformer as mods
+    x = torch.from_numpy(gu.make_input("x", (3, 40, 16), 95)).to(dev)
+    ctx = torch.from_numpy(gu.make_input("ctx", (3, 9, 64), 95)).to(dev)
+
+    def build():
+        return load_seeded(mods.ContinuousTransformer(dim=128, depth=3, dim_in=16, dim_out=16, dim_heads=64, cross_attend=True,
+                                                      cond_token_dim=64), 95, dev)
+
+    def loss_of(ct, second):
+        out, info = ct(x, context=ctx, return_info=True)
+        loss = out.square().mean()
+        if second:
+            loss = loss + 0.3 * info["hidden_states"][0].square().mean() + 0.2 * info["hidden_states"][1].mean()
+        return loss
+
+    for second in (False, True):
+        ref = build()
+        loss_of(ref, second).backward()
+        gref = {n: p.grad.clone() for n, p in ref.named_parameters()}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("KALLE_FUSE_BIAS_COLSUM", fuse)
+            ct = build()
+            tr = engine.DataParallelTrainer(ct, lr=0.0, optimizer="Adam")
+            for rep in range(2):
+                tr.backward(loss_of(ct, second))
+                torch.cuda.synchronize()
+                gmax = max(v.norm().item() for v in gref.values())
+                for n, _ in ct.named_parameters():
+                    a, b = tr.flat.grad_view(n), gref[n]
+                    err = (a - b).norm().item()
+                    assert err <= 5e-3 * max(b.norm().item(), 1e-2 * gmax), (second, fuse, rep, n, err, b.norm().item())
