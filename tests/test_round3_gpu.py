@@ -826,3 +826,74 @@ def test_fused_bias_column_sums_and_second_consumers(dev, monkeypatch):
                     a, b = tr.flat.grad_view(n), gref[n]
                     err = (a - b).norm().item()
                     assert err <= 5e-3 * max(b.norm().item(), 1e-2 * gmax), (second, fuse, rep, n, err, b.norm().item())
+
+
+def _llasa_fuzz_cases():
+    import random
+    rnd = random.Random(4242)
+    cases = []
+    for i in range(6):
+        H = rnd.choice([2, 3, 4, 6])
+        Hkv = rnd.choice([k for k in (1, 2, 3) if H % k == 0])
+        cases.append(dict(seed=500 + i, H=H, Hkv=Hkv, layers=rnd.choice([1, 2, 3]), inter=rnd.choice([192, 256, 448]),
+                          lat=rnd.choice([8, 16, 32]), B=rnd.choice([1, 2, 4]), L=rnd.choice([24, 64, 130, 257]),
+                          scaling=rnd.choice([True, False])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _llasa_fuzz_cases(), ids=lambda c: f"s{c['seed']}-H{c['H']}k{c['Hkv']}-L{c['layers']}-B{c['B']}-n{c['L']}")
+def test_llasa_configuration_fuzz(dev, tmp_path, c):
+    """model_sigmaVAE.Llasa over seeded random Llama shapes (2-6 heads over 1-3 kv heads, 1-3 layers, odd MLP widths, with and
+    without llama3 rope scaling) and ragged batches of 24-257 positions: both losses, the predicted means at the valid positions
+    and EVERY parameter gradient against the CPU oracle on the same weights"""
+    import json
+    import golden_util as gu
+    from test_modules_gpu import _Tok, _hf_grads
+    from kalle_audio_amd.model_sigmaVAE import Llasa
+    hid = 64 * c["H"]
+    llama = dict(vocab_size=300, hidden_size=hid, intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+                 num_attention_heads=c["H"], num_key_value_heads=c["Hkv"], head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0,
+                 max_position_embeddings=1024, tie_word_embeddings=True, attention_bias=False, mlp_bias=False, hidden_act="silu")
+    if c["scaling"]:
+        llama["rope_scaling"] = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                     original_max_position_embeddings=64)
+    lc = dict(latent_dim=c["lat"], tokenizer_len=310, llama=llama)
+    d = tmp_path / "llama_fuzz"
+    d.mkdir(exist_ok=True)
+    (d / "config.json").write_text(json.dumps(dict(llama, model_type="llama")))
+    m = Llasa({"llm_model_name_or_path": str(d), "latent_dim": c["lat"], "audio_proj_dim": hid}, _Tok(310), use_flash_attention=False)
+    lat, I, H, Hkv = c["lat"], c["inter"], c["H"], c["Hkv"]
+    names = [("audio_linear.bias", (hid,)), ("audio_linear.weight", (hid, lat)), ("base_model.model.embed_tokens.weight", (310, hid)),
+             ("base_model.model.norm.weight", (hid,)), ("distribution_linear.0.bias", (lat,)), ("distribution_linear.0.weight", (lat, hid)),
+             ("distribution_linear.2.bias", (lat,)), ("distribution_linear.2.weight", (lat, lat))]
+    for i in range(c["layers"]):         # the reference's (HF) names: the drop-in fuses q | k | v and gate | up at load time
+        pre = f"base_model.model.layers.{i}."
+        names += [(pre + "input_layernorm.weight", (hid,)), (pre + "post_attention_layernorm.weight", (hid,)),
+                  (pre + "mlp.down_proj.weight", (hid, I)), (pre + "mlp.gate_proj.weight", (I, hid)), (pre + "mlp.up_proj.weight", (I, hid)),
+                  (pre + "self_attn.q_proj.weight", (H * 64, hid)), (pre + "self_attn.k_proj.weight", (Hkv * 64, hid)),
+                  (pre + "self_attn.v_proj.weight", (Hkv * 64, hid)), (pre + "self_attn.o_proj.weight", (hid, H * 64))]
+    st = gu.make_state(names, c["seed"])
+    sd_gpu = {k: torch.from_numpy(v) for k, v in st.items()}
+    sd_gpu["base_model.lm_head.weight"] = sd_gpu["base_model.model.embed_tokens.weight"]
+    m.load_state_dict(sd_gpu)
+    m = m.to(dev)
+    sd = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in st.items()}
+    bnp = gu.llasa_batch_long(lc, c["seed"], B=c["B"], L=c["L"])
+    eps_np = gu.make_input("llasa_eps", tuple(bnp["audio_latents"].shape), c["seed"])
+    ref = ko.llasa_forward(sd, lc, {k: torch.from_numpy(v) for k, v in bnp.items()}, torch.from_numpy(eps_np))
+    (ref["audio_loss"] * 1.0 + ref["end_loss"] * 0.5).backward()
+    b = {k: torch.from_numpy(v).to(dev) for k, v in bnp.items()}
+    out = m(b["input_ids"], b["audio_latents"], b["audio_distribution_l"], b["ids_mask"], b["audio_mask"], b["target_mask"],
+            b["end_mask"], noise=torch.from_numpy(eps_np).to(dev))
+    for k in ("audio_loss", "end_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    valid = ((b["ids_mask"] + b["audio_mask"]) > 0).cpu()
+    assert rel(out["pre_mean"].float().cpu()[valid], ref["pre_mean"].detach()[valid]) < 1.5e-2
+    (out["audio_loss"] * 1.0 + out["end_loss"] * 0.5).backward()
+    g = _hf_grads(m)
+    gmax = max(v.grad.norm().item() for v in sd.values() if v.grad is not None)
+    for n, v in sd.items():
+        if v.grad is None:
+            continue
+        err = (g[n].float().cpu() - v.grad).norm().item()
+        assert err <= 4e-2 * max(v.grad.norm().item(), 2e-2 * gmax), (n, err, v.grad.norm().item())
