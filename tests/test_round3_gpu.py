@@ -897,3 +897,52 @@ def test_llasa_configuration_fuzz(dev, tmp_path, c):
             continue
         err = (g[n].float().cpu() - v.grad).norm().item()
         assert err <= 4e-2 * max(v.grad.norm().item(), 2e-2 * gmax), (n, err, v.grad.norm().item())
+
+
+def _melvae_fuzz_cases():
+    import random
+    rnd = random.Random(99)
+    cases = []
+    for i in range(6):
+        n = rnd.choice([2, 3])
+        up = [rnd.choice([2, 3, 4, 5]) for _ in range(n)]
+        rk = [rnd.choice([3, 5, 7]) for _ in range(2)]
+        r1 = rnd.choice([True, False])
+        cases.append(dict(seed=600 + i, h=dict(
+            latent_dim=rnd.choice([4, 8, 12]), use_vae=True, downsample_channels=[12, 16, 24, 32][:n + 1],
+            downsample_rates=list(reversed(up)), upsample_rates=up, upsample_kernel_sizes=[2 * u for u in up],
+            upsample_initial_channel=rnd.choice([24, 32, 48]), resblock="1" if r1 else "2", resblock_kernel_sizes=rk,
+            resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]] if r1 else [[1, 3], [1, 2]],
+            activation=rnd.choice(["snakebeta", "snake"]), snake_logscale=rnd.choice([True, False]),
+            causal=rnd.choice([True, False]), flow_hidden_channels=rnd.choice([8, 16])),
+            frames=rnd.choice([9, 40, 173]), B=rnd.choice([1, 2, 3])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _melvae_fuzz_cases(), ids=lambda c: f"s{c['seed']}-up{'x'.join(map(str, c['h']['upsample_rates']))}-rb{c['h']['resblock']}-f{c['frames']}")
+def test_melvae_configuration_fuzz(dev, c):
+    """backup/flows.py BigVGANFlowVAE over seeded random hyper-parameters (2-3 levels, up / down rates 2-5, kernel sizes 3-7, AMP
+    block 1 / 2, snake / snakebeta, log-scale or not, causal or 'same' padding, odd channel widths) and lengths that fit no tile:
+    encoder and decoder against the CPU oracle on the same weights (fp32 conv path: 2e-4; the anti-aliased activation is the
+    published algorithm on both sides - parity of that piece is unpinned)"""
+    import golden_util as gu
+    from test_modules_gpu import load_seeded
+    from kalle_audio_amd.flows import BigVGANFlowVAE
+    h = c["h"]
+    vae = load_seeded(BigVGANFlowVAE(h), c["seed"], dev)
+    sd = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    ratio = 1
+    for u in h["upsample_rates"]:
+        ratio *= u
+    z = torch.from_numpy(gu.make_input("zz", (c["B"], h["latent_dim"], c["frames"]), c["seed"]))
+    want = ko.melvae_decode(sd, z, h)
+    with torch.no_grad():
+        got = vae.inference_from_latents(z.to(dev), do_sample=False)
+    # ('same' padding with an odd rate: (k - u) // 2 leaves one sample more per level than frames x rate - as the reference's)
+    assert got.shape == want.shape and abs(got.shape[-1] - c["frames"] * ratio) <= 2 * ratio, (tuple(got.shape), tuple(want.shape))
+    assert rel(got, want) < 2e-4, rel(got, want)
+    wav = torch.from_numpy(gu.make_input("ww", (c["B"], 1, c["frames"] * ratio + 3), c["seed"], 0.5))
+    want = ko.melvae_encoder(ko._sub(sd, "audio_encoder."), wav, h["downsample_rates"])
+    with torch.no_grad():
+        got = vae.extract_latents(wav.to(dev))
+    assert got.shape == want.shape and rel(got, want) < 1e-4, (tuple(got.shape), tuple(want.shape), rel(got, want))
