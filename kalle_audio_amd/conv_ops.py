@@ -120,6 +120,26 @@ def snake_beta(x, alpha, beta, logscale=True):
     return y
 
 
+def activate(x, act, alpha=None, beta=None, logscale=True):
+    """act(x) as a tensor of its own (the VAE's conv kernels apply their input activation on the fly; the weight gradient of a
+    transposed conv wants the activated input as its scalar operand): codes 0 none / 1 SnakeBeta / 2 ELU, x fp32 [B, C, L]"""
+    if not act:
+        return x
+    if act == 1:
+        return snake_beta(x.contiguous(), alpha, beta, logscale)
+    lib = _lib.load()
+    x = x.contiguous()
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    ia = _act_struct(act, alpha, beta, logscale, 0.0)
+    step = max(1, 65535 // C)                     # (kalle_conv_pad_act puts B * C rows on one grid axis)
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        check(lib.kalle_conv_pad_act(_p(x[b0:b0 + nb]), _p(y[b0:b0 + nb]), nb, C, L, L, 0, ctypes.addressof(ia), 1, _stream()),
+              "kalle_conv_pad_act")
+    return y
+
+
 def kaiser_sinc_filter12(device, cutoff=0.25, half_width=0.3, kernel_size=12):
     """the 12-tap low-pass of alias-free-torch's UpSample1d / DownSample1d at ratio 2 (cutoff 0.5/2, half-width 0.6/2):
     kaiser window (beta from the attenuation implied by the transition width) x sinc, normalised to unit sum."""

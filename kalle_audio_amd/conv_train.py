@@ -175,8 +175,10 @@ class ActConvFn(torch.autograd.Function):
                 conv_wgrad(gy, x, dw, K=K, stride=stride, padding=pad, dilation=dil, act_on=0, act=act, alpha=a32, beta=be32,
                            logscale=ls)
             else:
-                conv_wgrad(x, gy, dw, K=K, stride=stride, padding=pad, dilation=1, act_on=1, act=act, alpha=a32, beta=be32,
-                           logscale=ls)
+                # (the activated input is the SCALAR operand of the LDS-staged kernel: materialised once instead of re-applying
+                # the activation at every use)
+                xa = conv_ops.activate(x, act, a32, be32, ls)
+                conv_wgrad(xa, gy, dw, K=K, stride=stride, padding=pad, dilation=1, act_on=1, act=0)
             dv, dg = weight_norm_bwd(dw, v, g)
         db = channel_sum(gy) if has_bias and ctx.needs_input_grad[3] else None
         # ---- through the input activation

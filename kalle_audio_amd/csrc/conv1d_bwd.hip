@@ -11,6 +11,8 @@
 //   activation       dx, dalpha, dbeta : act_bwd_kernel (SnakeBeta / ELU), per-channel reductions added atomically;
 //   bias / tanh                : chan_sum_kernel, tanh_bwd_kernel;
 //   weight norm      dg, dv    : wn_bwd_kernel (w = g v / ||v||, one workgroup per slice of dim 0).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -112,6 +114,107 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                 if (lane == 0 && cu0 + i < CU && cv0 + j < CV)
                     atomicAdd(dW + ((int64_t)(cu0 + i) * CV + (cv0 + j)) * K + k, s);
             }
+}
+
+// ---- weight gradient, LDS-staged (round 3) -----------------------------------------------------------------------------------
+// The kernel above reads every V element K times through per-lane global loads and re-applies the input activation (a sine for
+// SnakeBeta) on each of them: 28 loads and 28 activations per 112 FMAs - the VAE's backward pass took 17 x its forward.  Here the
+// roles follow the forward kernels: a LANE owns one V channel (a wave 64 of them), its accumulators are TU x K partial sums for
+// TU U channels, and the reduction walks positions.  Per tile of P positions the workgroup stages the V span it touches
+// ((P - 1) stride + (K - 1) dil + 1 positions x 64 channels) into LDS ONCE - coalesced along positions, activated once per
+// element, stored position-major with a 65-float row so that both the transposing store and the channel-per-lane reads are
+// conflict-free - and its 4 waves (4 x TU U channels) share it.  The U values of a step are wave-uniform: scalar loads through
+// the constant address space, fed to v_fma as SGPR operands.  At the end a wave lays each U channel's [64 cv][K] block out in
+// LDS exactly as dW stores it and adds it with contiguous 256-byte atomics.
+typedef const __attribute__((address_space(4))) float* cfloat_p;
+
+template <int TU, int K>      // K: the tap count itself (1, 4, 7, 8, 16 - what the VAEs use): every tap loop unrolls without a branch
+__global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                             float* __restrict__ dW, int CU, int CV, int MU, int LV, int stride,
+                                                             int pad, int dil, int act, const float* __restrict__ alpha,
+                                                             const float* __restrict__ beta, int logscale, int chunks_per_b,
+                                                             int per_wg, int P, int rows) {
+    extern __shared__ float wg_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cv0 = blockIdx.y * 64, cu0 = blockIdx.z * (4 * TU) + wave * TU;
+    const int b = blockIdx.x / chunks_per_b, ch = blockIdx.x - b * chunks_per_b;
+    const int m_begin = ch * per_wg, m_end = min(m_begin + per_wg, MU);
+    float acc[TU][K];
+#pragma unroll
+    for (int t = 0; t < TU; ++t)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[t][k] = 0.f;
+    // row pointers of this wave's TU channels of U (rows past CU are clamped: their sums are never stored)
+    cfloat_p up[TU];
+#pragma unroll
+    for (int t = 0; t < TU; ++t)
+        up[t] = reinterpret_cast<cfloat_p>(reinterpret_cast<uintptr_t>(U)) + ((int64_t)b * CU + min(cu0 + t, CU - 1)) * MU;
+    for (int m0 = m_begin; m0 < m_end; m0 += P) {
+        __syncthreads();                                   // the previous tile has been read
+        const int l0 = m0 * stride - pad;
+        for (int j = 0; j < 16; ++j) {
+            const int cvl = wave * 16 + j, c = cv0 + cvl;
+            float a = 0.f, ib = 0.f;
+            if (act == 1 && c < CV) {
+                a = alpha[c];
+                float bb = beta[c];
+                if (logscale) { a = __expf(a); bb = __expf(bb); }
+                ib = 1.f / (bb + 1e-9f);
+            }
+            const float* vr = V + ((int64_t)b * CV + min(c, CV - 1)) * LV;
+            for (int r = lane; r < rows; r += 64) {
+                const int l = l0 + r;
+                float t = 0.f;
+                if (c < CV && l >= 0 && l < LV) {
+                    t = vr[l];
+                    if (act) t = act_fwd(t, act, a, ib);
+                }
+                wg_lds[r * 65 + cvl] = t;
+            }
+        }
+        __syncthreads();
+        const int np = min(P, m_end - m0);
+        for (int i0 = 0; i0 < np; i0 += 4) {
+            float u[TU][4];
+            const int m = m0 + i0;
+            if (m + 3 < m_end) {                           // (uniform) four positions of every row: scalar loads off one base each
+#pragma unroll
+                for (int t = 0; t < TU; ++t) {
+                    const cfloat_p q4 = up[t] + m;
+                    u[t][0] = q4[0]; u[t][1] = q4[1]; u[t][2] = q4[2]; u[t][3] = q4[3];
+                }
+            } else {                                       // the last, partial block of this workgroup's range
+#pragma unroll
+                for (int t = 0; t < TU; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) u[t][q] = m + q < m_end ? up[t][min(m + q, MU - 1)] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* tr = wg_lds + (i0 + q) * stride * 65 + lane;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float v = tr[k * dil * 65];
+#pragma unroll
+                    for (int t = 0; t < TU; ++t) acc[t][k] = fmaf(u[t][q], v, acc[t][k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* ep = wg_lds + wave * (64 * K);
+#pragma unroll
+    for (int t = 0; t < TU; ++t) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) ep[lane * K + k] = acc[t][k];
+        const int cu = cu0 + t;
+        if (cu < CU) {
+            float* dst = dW + ((int64_t)cu * CV + cv0) * K;
+            for (int e = lane; e < 64 * K; e += 64)
+                if (cv0 + e / K < CV) atomicAdd(dst + e, ep[e]);
+        }
+    }
 }
 
 // ---- activation backward: dx = g * act'(x); SnakeBeta also d alpha, d beta (blocks.py:301-339) ----------------------------------
@@ -239,6 +342,40 @@ extern "C" int kalle_conv_wgrad(const float* U, const float* V, float* dW, int B
         if (code < 0 || code > 2 || (code == 1 && (!al || !be))) return KALLE_ERR_ARG;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // LDS-staged kernel: the activation (if any) sits on V, V has at least a quarter of a wave's worth of channels
+    static const bool lds_off = getenv("KALLE_CONV_WGRAD_V1") != nullptr;       // experiment switch: the per-lane-load kernel
+    if (!lds_off && (act_on == 0 || code == 0) && CV >= 16) {
+        int P = 64;
+        auto rows_of = [&](int p) { return (p - 1) * stride + (ksize - 1) * dilation + 1; };
+        while (P > 4 && rows_of(P) * 65 * 4 > 48 * 1024) P >>= 1;
+        const int rows = rows_of(P);
+        auto launch2 = [&](auto tu_c, auto k_c) {
+            constexpr int TU = decltype(tu_c)::value, KT = decltype(k_c)::value;
+            const int ty = (CV + 63) / 64, tz = (CU + 4 * TU - 1) / (4 * TU);
+            if (ty > 65535 || tz > 65535) return KALLE_ERR_ARG;
+            // ~1536 workgroups in all, at least 4 tiles of positions each (the final atomics cost what ~100 positions do)
+            int64_t cpb = (1536 + (int64_t)ty * tz * B - 1) / ((int64_t)ty * tz * B);
+            const int64_t max_cpb = (MU + 4 * P - 1) / (4 * P);
+            cpb = cpb < 1 ? 1 : (cpb > max_cpb ? max_cpb : cpb);
+            const int per_wg = (int)(((MU + cpb - 1) / cpb + P - 1) / P * P);
+            const int chunks = (MU + per_wg - 1) / per_wg;
+            if ((int64_t)chunks * B > 0x7fffffff) return KALLE_ERR_ARG;
+            const int lds = std::max(rows * 65 * 4, 4 * 64 * KT * 4);
+            KALLE_LAUNCH((conv_wgrad_lds_kernel<TU, KT>), dim3(chunks * B, ty, tz), dim3(256), lds, st, U, V, dW, CU, CV, MU, LV,
+                         stride, padding, dilation, code, al, be, logscale, chunks, per_wg, P, rows);
+            return kalle_check_launch();
+        };
+        using I16_ = std::integral_constant<int, 16>;
+        using I8_ = std::integral_constant<int, 8>;
+        switch (ksize) {
+            case 1: return launch2(I16_{}, std::integral_constant<int, 1>{});
+            case 4: return launch2(I16_{}, std::integral_constant<int, 4>{});
+            case 7: return launch2(I16_{}, std::integral_constant<int, 7>{});
+            case 8: return launch2(I16_{}, I8_{});
+            case 16: return launch2(I8_{}, I16_{});
+            default: break;                  // other tap counts: the per-lane-load kernel below
+        }
+    }
     const int64_t total = (int64_t)B * MU;
     // position ranges: enough workgroups to fill the chip a few times over, at least 2048 positions each (the final fold costs
     // TU*TV*K shuffles + atomics per wave)

@@ -946,3 +946,63 @@ def test_melvae_configuration_fuzz(dev, c):
     with torch.no_grad():
         got = vae.extract_latents(wav.to(dev))
     assert got.shape == want.shape and rel(got, want) < 1e-4, (tuple(got.shape), tuple(want.shape), rel(got, want))
+
+
+def _conv_wgrad_cases():
+    import random
+    rnd = random.Random(31)
+    cases = [dict(kind="conv", K=7, s=1, d=9, Cin=128, Cout=128, L=3000, B=2, act=1), dict(kind="conv", K=1, s=1, d=1, Cin=96, Cout=160, L=777, B=3, act=2),
+             dict(kind="conv", K=4, s=2, d=1, Cin=40, Cout=72, L=1001, B=2, act=1), dict(kind="conv", K=8, s=4, d=1, Cin=64, Cout=130, L=2049, B=1, act=0),
+             dict(kind="conv", K=16, s=8, d=1, Cin=48, Cout=96, L=1283, B=2, act=1), dict(kind="convT", K=16, s=8, d=1, Cin=96, Cout=40, L=97, B=2, act=1),
+             dict(kind="convT", K=8, s=4, d=1, Cin=130, Cout=64, L=211, B=1, act=2), dict(kind="convT", K=4, s=2, d=1, Cin=32, Cout=32, L=500, B=3, act=0),
+             dict(kind="conv", K=7, s=1, d=3, Cin=2, Cout=64, L=900, B=2, act=0), dict(kind="conv", K=5, s=1, d=2, Cin=64, Cout=64, L=300, B=2, act=1)]
+    for i in range(4):
+        cases.append(dict(kind="conv", K=7, s=1, d=rnd.choice([1, 3, 9]), Cin=rnd.choice([17, 64, 200]), Cout=rnd.choice([24, 65, 128]),
+                          L=rnd.choice([63, 450, 5000]), B=rnd.choice([1, 2]), act=rnd.choice([0, 1, 2])))
+    return cases
+
+
+@pytest.mark.parametrize("c", _conv_wgrad_cases(), ids=lambda c: f"{c['kind']}-K{c['K']}s{c['s']}d{c['d']}-{c['Cin']}x{c['Cout']}-L{c['L']}-a{c['act']}")
+def test_conv_weight_gradient_kernels_vs_torch(dev, c):
+    """kalle_conv_wgrad (round 3: LDS-staged kernel, lane = V channel, U as scalar operands; the per-lane-load kernel remains for
+    fewer than 16 V channels and odd tap counts): dW of Conv1d and ConvTranspose1d with the input activation (SnakeBeta / ELU /
+    none) against torch autograd in fp64 - strides 1-8, dilations 1-9, channel counts that do not fill the 64-lane / 64-channel
+    tiles, lengths that end inside a position tile"""
+    import torch.nn.functional as F
+    from kalle_audio_amd import conv_ops
+    from kalle_audio_amd.conv_train import conv_wgrad
+    g = torch.Generator().manual_seed(7)
+    K, s_, d, Cin, Cout, L, B, act = c["K"], c["s"], c["d"], c["Cin"], c["Cout"], c["L"], c["B"], c["act"]
+    x = torch.randn(B, Cin, L, generator=g, dtype=torch.float64)
+    alpha = (torch.randn(Cin, generator=g, dtype=torch.float64) * 0.3) if act == 1 else None
+    beta = (torch.randn(Cin, generator=g, dtype=torch.float64) * 0.3) if act == 1 else None
+
+    def actf(t):
+        if act == 1:
+            a, b_ = alpha.exp()[None, :, None], beta.exp()[None, :, None]
+            return t + torch.sin(t * a) ** 2 / (b_ + 1e-9)
+        return F.elu(t) if act == 2 else t
+
+    if c["kind"] == "conv":
+        pad = (K - 1) * d // 2 if s_ == 1 else (s_ + 1) // 2
+        w = torch.randn(Cout, Cin, K, generator=g, dtype=torch.float64, requires_grad=True)
+        y = F.conv1d(actf(x), w, stride=s_, padding=pad, dilation=d)
+    else:
+        pad = (s_ + 1) // 2
+        w = torch.randn(Cin, Cout, K, generator=g, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose1d(actf(x), w, stride=s_, padding=pad)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xf, gyf = x.float().to(dev), gy.float().to(dev)
+    a32 = alpha.float().to(dev) if alpha is not None else None
+    b32 = beta.float().to(dev) if beta is not None else None
+    dw = torch.zeros(w.shape, device=dev)
+    if c["kind"] == "conv":
+        conv_wgrad(gyf, xf, dw, K=K, stride=s_, padding=pad, dilation=d, act_on=0, act=act, alpha=a32, beta=b32, logscale=True)
+    else:
+        conv_wgrad(conv_ops.activate(xf, act, a32, b32, True), gyf, dw, K=K, stride=s_, padding=pad, dilation=1, act_on=1, act=0)
+    assert rel(dw, w.grad.float()) < 2e-5, rel(dw, w.grad.float())
+    if c["kind"] == "convT" and act:      # the in-kernel activation of the scalar-side operand (per-lane-load kernel) still agrees
+        dw2 = torch.zeros(w.shape, device=dev)
+        conv_wgrad(xf, gyf, dw2, K=K, stride=s_, padding=pad, dilation=1, act_on=1, act=act, alpha=a32, beta=b32, logscale=True)
+        assert rel(dw2, w.grad.float()) < 2e-5
