@@ -460,7 +460,9 @@ int kalle_gauss_kl2_bwd(const float* pred, const float* label_mean, const float*
  *   dW[cu][cv][k] += sum_{b, m} U[b, cu, m] * V[b, cv, m*stride - padding + k*dilation]
  *   Conv1d: U = dy [B][Cout][Lout], V = x [B][Cin][Lin]  -> dW in the module's [Cout][Cin][K] layout (act_on 0)
  *   ConvTranspose1d: U = x [B][Cin][Lin], V = dy [B][Cout][Lout] -> dW [Cin][Cout][K]            (act_on 1)
- *   `act` (code 0 / 1 SnakeBeta / 2 ELU) is the conv's INPUT activation, applied on the fly to x = V (act_on 0) or U (1). */
+ *   `act` (code 0 / 1 SnakeBeta / 2 ELU) is the conv's INPUT activation, applied on the fly to x = V (act_on 0) or U (1).
+ *   With the activation on V (or none), >= 16 V channels and 1 / 4 / 7 / 8 / 16 taps the LDS-staged kernel runs (the V span of a
+ *   position tile staged and activated once, U as scalar operands); a transposed conv's caller passes act(x) as U with act 0. */
 int kalle_conv_wgrad(const float* U, const float* V, float* dW, int B, int CU, int CV, int MU, int LV, int ksize, int stride,
                      int padding, int dilation, int act_on, const kalle_act* act, void* stream);
 /* dx = g * act'(x) for x, g [B][C][L] fp32; SnakeBeta (blocks.py:301-339) also adds d alpha, d beta [C] atomically
