@@ -220,6 +220,36 @@ __device__ __forceinline__ void attn_stamp(const AttnParams& p, int tid, int idx
 // ================================================================================================ forward
 // QT = 16-row query tiles per wave: 2 -> 4 waves per workgroup (wave = 32 queries), 1 -> 8 waves (wave = 16 queries,
 // <= 128 VGPRs so two workgroups = 16 waves share a CU and hide each other's load -> LDS -> MFMA latency chain)
+// ---- stores of an owner row's 64 features from the MFMA result layout ------------------------------------------------------------
+// Lane (g, li) holds features 4g .. 4g + 3 of each 16-feature block dt of row li: straight from that layout a lane writes 8 bytes
+// per block - 32 contiguous bytes per row and store instruction.  Lanes g and g ^ 1 trade blocks instead (v_permlane16_swap_b32:
+// the odd 16-lane rows of one register against the even rows of the other, one instruction per traded dword pair), so that each
+// owns 8 consecutive features of two blocks: 16-byte stores, 64 contiguous bytes per row and instruction, half the store
+// instructions (the GEMM epilogues' lesson: the store side is bound by the number of store instructions, not by bytes).
+// `row`: the row's first feature (no lane offset).  Partners share li, i.e. the row and its validity: safe under a row guard.
+#ifndef KALLE_ATTN_ST16
+#define KALLE_ATTN_ST16 1
+#endif
+__device__ __forceinline__ void store_row64(bf16_t* row, const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, int g) {
+    const f32x4 v[4] = {v0, v1, v2, v3};
+    uint32_t w[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { w[dt][0] = pack_bf16x2(v[dt][0], v[dt][1]); w[dt][1] = pack_bf16x2(v[dt][2], v[dt][3]); }
+#if KALLE_ATTN_ST16
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        // even g keeps block 2 pr and receives the partner's; odd g keeps block 2 pr + 1 and receives the partner's (lower features)
+        const auto a = __builtin_amdgcn_permlane16_swap(w[2 * pr][0], w[2 * pr + 1][0], false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(w[2 * pr][1], w[2 * pr + 1][1], false, false);
+        *reinterpret_cast<i32x4*>(row + 16 * (2 * pr + (g & 1)) + 4 * (g & ~1)) = i32x4{(int)a[0], (int)c[0], (int)a[1], (int)c[1]};
+    }
+#else
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<i32x2*>(row + 16 * dt + 4 * g) = i32x2{(int)w[dt][0], (int)w[dt][1]};
+#endif
+}
+
+
 template <int QT>
 __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int NT = 128 / (16 * QT) * 64;
@@ -405,14 +435,8 @@ __global__ __launch_bounds__(128 / (16 * QT) * 64, QT == 1 ? 4 : 2) void attn_fw
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         const int qi = q0 + wave * (16 * QT) + 16 * qt + li;
         if (qi < p.Nq) {
-            bf16_t* op = p.out + ((int64_t)b * p.Nq + qi) * p.ldo + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                i32x2 w;
-                w[0] = (int)pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
-                w[1] = (int)pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
-                *reinterpret_cast<i32x2*>(op + 16 * dt) = w;
-            }
+            store_row64(p.out + ((int64_t)b * p.Nq + qi) * p.ldo + h * 64, o[0][qt] * inv, o[1][qt] * inv, o[2][qt] * inv,
+                        o[3][qt] * inv, g);
             if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.Nq + qi] = m[qt] * SM_SCALE + __logf(lt);
         }
     }
@@ -870,18 +894,8 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     }
                 }
             }
-            bf16_t* dkp = p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + h * 64 + 4 * g;
-            bf16_t* dvp = p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                i32x2 w;
-                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
-                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
-                *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
-                w[0] = (int)pack_bf16x2(g1[dt][0], g1[dt][1]);
-                w[1] = (int)pack_bf16x2(g1[dt][2], g1[dt][3]);
-                *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
-            }
+            store_row64(p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + h * 64, g2[0], g2[1], g2[2], g2[3], g);
+            store_row64(p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + h * 64, g1[0], g1[1], g1[2], g1[3], g);
         }
     }
 
@@ -944,14 +958,7 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
             }
             attn_stamp(p, tid, 5);
-            bf16_t* dqp = p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                i32x2 w;
-                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
-                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
-                *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
-            }
+            store_row64(p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64, g2[0], g2[1], g2[2], g2[3], g);
         }
     }
     if (p.stamps) {
@@ -1113,18 +1120,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p
         }
         const int oi = orow + li;
         if (oi < nmain) {
-            bf16_t* dkp = p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + hk * 64 + 4 * g;
-            bf16_t* dvp = p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + hk * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                i32x2 w;
-                w[0] = (int)pack_bf16x2(g2[dt][0], g2[dt][1]);
-                w[1] = (int)pack_bf16x2(g2[dt][2], g2[dt][3]);
-                *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
-                w[0] = (int)pack_bf16x2(g1[dt][0], g1[dt][1]);
-                w[1] = (int)pack_bf16x2(g1[dt][2], g1[dt][3]);
-                *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
-            }
+            store_row64(p.dk + ((int64_t)b * Nk + oi) * p.ldk + p.k_off + hk * 64, g2[0], g2[1], g2[2], g2[3], g);
+            store_row64(p.dv + ((int64_t)b * Nk + oi) * p.ldv + p.v_off + hk * 64, g1[0], g1[1], g1[2], g1[3], g);
         }
     }
 
@@ -1188,14 +1185,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p
             if (tail > 0) stream_keys(RQ, RD, 112, std::true_type{});
             const int oi = orow + li;
             if (oi < N) {
-                bf16_t* dqp = p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64 + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    i32x2 w;
-                    w[0] = (int)pack_bf16x2(gq[dt][0], gq[dt][1]);
-                    w[1] = (int)pack_bf16x2(gq[dt][2], gq[dt][3]);
-                    *reinterpret_cast<i32x2*>(dqp + 16 * dt) = w;
-                }
+                store_row64(p.dq + ((int64_t)b * N + oi) * p.ldq + p.q_off + h * 64, gq[0], gq[1], gq[2], gq[3], g);
             }
         }
         if (tail > 0 && wave == 7) {        // the ninth owner tile: rows 112..127 of the Q / dO images in the key role
@@ -1224,18 +1214,8 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_fused_gqa_kernel(AttnParams p
                 const int row = 112 + li;
                 if (row >= trow0) {
                     const int key = 128 + (row - trow0);
-                    bf16_t* dkp = p.dk + ((int64_t)b * Nk + key) * p.ldk + p.k_off + hk * 64 + 4 * g;
-                    bf16_t* dvp = p.dv + ((int64_t)b * Nk + key) * p.ldv + p.v_off + hk * 64 + 4 * g;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        i32x2 w;
-                        w[0] = (int)pack_bf16x2(gt2[dt][0], gt2[dt][1]);
-                        w[1] = (int)pack_bf16x2(gt2[dt][2], gt2[dt][3]);
-                        *reinterpret_cast<i32x2*>(dkp + 16 * dt) = w;
-                        w[0] = (int)pack_bf16x2(gt1[dt][0], gt1[dt][1]);
-                        w[1] = (int)pack_bf16x2(gt1[dt][2], gt1[dt][3]);
-                        *reinterpret_cast<i32x2*>(dvp + 16 * dt) = w;
-                    }
+                    store_row64(p.dk + ((int64_t)b * Nk + key) * p.ldk + p.k_off + hk * 64, gt2[0], gt2[1], gt2[2], gt2[3], g);
+                    store_row64(p.dv + ((int64_t)b * Nk + key) * p.ldv + p.v_off + hk * 64, gt1[0], gt1[1], gt1[2], gt1[3], g);
                 }
             }
         }

@@ -527,7 +527,11 @@ extern "C" int kalle_layernorm_fwd(const void* x, int x_dtype, const float* gamm
 }
 
 extern "C" int kalle_layernorm_bwd_parts(int rows) {
-    const int b = (rows + 3) / 4;
+    // rows per workgroup (4 waves = 4 rows per pass).  Every workgroup ends with 2 D atomics (or a partial row) whatever it did, so
+    // below ~8000 rows - where the 1024-workgroup cap does not bind - 8 rows per workgroup instead of 4 halve that tail: the B = 16
+    // train step (2016 rows, 72 launches) 31.4 -> 30.9 ms, 16 rows 31.1 (too few waves in flight); KALLE_LN_BWD_RPB to experiment
+    static const int rpb = getenv("KALLE_LN_BWD_RPB") ? atoi(getenv("KALLE_LN_BWD_RPB")) : 8;
+    const int b = (rows + rpb - 1) / (rpb > 0 ? rpb : 4);
     return b < LN_BWD_MAX_BLOCKS ? (b > 0 ? b : 1) : LN_BWD_MAX_BLOCKS;
 }
 
