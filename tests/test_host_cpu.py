@@ -313,3 +313,17 @@ class _Fake:
 
     def numel(self):
         return self.n
+
+
+def test_layernorm_backward_workgroup_count():
+    """kalle_layernorm_bwd_parts is host arithmetic (no GPU call): the number of partial rows the caller must provide = the launch's
+    workgroup count - 8 rows per workgroup below the 1024-workgroup cap (B = 16 per GPU: 2016 rows), the cap above it"""
+    from kalle_audio_amd import _lib
+    lib = _lib.load()
+    if os.environ.get("KALLE_LN_BWD_RPB"):
+        pytest.skip("experiment switch set")
+    assert lib.kalle_layernorm_bwd_parts(1) == 1
+    assert lib.kalle_layernorm_bwd_parts(8) == 1 and lib.kalle_layernorm_bwd_parts(9) == 2
+    assert lib.kalle_layernorm_bwd_parts(2016) == 252
+    assert lib.kalle_layernorm_bwd_parts(8064) == 1008
+    assert lib.kalle_layernorm_bwd_parts(32256) == 1024 and lib.kalle_layernorm_bwd_parts(10 ** 6) == 1024
