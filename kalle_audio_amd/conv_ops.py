@@ -60,7 +60,14 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
     # few positions, many channels (the top of the VAE, all of a single-clip decode): channels-per-lane kernel over a padded,
     # pre-activated copy of x.  Chosen when the position-per-lane tiling would leave most CUs without a workgroup.
     want = os.environ.get("KALLE_CONV_CFIRST")
-    small = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B < 256 and (Cout >= 256 or (Cout >= 64 and Lout * B <= 1024))
+    if Cout >= 256 and stride == 1:
+        # The position-per-lane kernel runs these layers in 8-wave workgroups of 128 channels x 512 positions (256 for k = 1): one
+        # round of them takes the same time whether 100 or 256 exist, while the channels-per-lane kernel scales with the work
+        # (tools/cfirst_vs_v2.sh, 1024 channels x 1720 positions, k = 7: B = 4 -> 128 workgroups 2316 us against 1820; B = 5 -> 160
+        # workgroups 2262 against 2560; 512 channels x 13760, k = 1, B = 1 -> 216 workgroups 162 us against 222)
+        small = -(-Lout // (256 if K == 1 else 512)) * -(-Cout // 128) * B < 160
+    else:
+        small = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B < 256 and (Cout >= 256 or (Cout >= 64 and Lout * B <= 1024))
     if ((stride == 1 or dilation == 1) and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
             and (want == "1" or (want is None and small))):
         Lp = lib.kalle_conv_pad_len(Lout, K, stride, padding, dilation)
