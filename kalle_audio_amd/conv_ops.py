@@ -100,7 +100,10 @@ def conv_transpose1d(x, w_packed, bias, *, Cout, K, stride, padding, act=0, alph
     ep = _epilogue(None, 1.0, False, False, post_act, y_raw)
     want = os.environ.get("KALLE_CONV_CFIRST")
     nq = (Lout - 1 + padding) // stride + 1
-    small = ((nq + 511) // 512) * ((Cout + 63) // 64) * B * stride < 1024 and Cout >= 256
+    # (tools/cfirst_vs_v2.sh: at 512+ output channels the channels-per-lane kernel holds 50-70 TFLOP/s where the phase-per-workgroup
+    # kernel needs far more positions to get there - 2048 -> 1024 x 215, B = 8: 2082 against 3463 us; 1024 -> 512 x 1720, B = 8: 3290
+    # against 3878; at 256 channels the two cross near 1500: 512 -> 256 x 13760, B = 3: 1465 against 1551, B = 4: 1870 against 1806)
+    small = ((nq + 511) // 512) * ((Cout + 63) // 64) * B * stride < (4096 if Cout >= 512 else 1536) and Cout >= 256
     if (trim >= 0 and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
             and (want == "1" or (want is None and small))):
         Lp = lib.kalle_convT_pad_len(Lout, K, stride, padding)
