@@ -60,14 +60,23 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
     # few positions, many channels (the top of the VAE, all of a single-clip decode): channels-per-lane kernel over a padded,
     # pre-activated copy of x.  Chosen when the position-per-lane tiling would leave most CUs without a workgroup.
     want = os.environ.get("KALLE_CONV_CFIRST")
-    if Cout >= 256 and stride == 1:
+    nwg64 = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B
+    if stride > 1:
+        # strided convs (the encoder's down-samplers): the position-per-lane kernels reach 16-25 TFLOP/s at stride 8 and 38-46 at
+        # stride 4, the channels-per-lane kernel 43-57 at every batch size measured (512 -> 1024, k = 16, stride 8, 13760 inputs,
+        # B = 4: 5388 against 2379 us; 1024 -> 2048 x 1720, B = 8: 7237 against 2166; 256 -> 512, k = 8, stride 4, B = 8: 5021 against 3876)
+        small = Cout >= 256
+    elif Cout >= 256:
         # The position-per-lane kernel runs these layers in 8-wave workgroups of 128 channels x 512 positions (256 for k = 1): one
         # round of them takes the same time whether 100 or 256 exist, while the channels-per-lane kernel scales with the work
         # (tools/cfirst_vs_v2.sh, 1024 channels x 1720 positions, k = 7: B = 4 -> 128 workgroups 2316 us against 1820; B = 5 -> 160
         # workgroups 2262 against 2560; 512 channels x 13760, k = 1, B = 1 -> 216 workgroups 162 us against 222)
         small = -(-Lout // (256 if K == 1 else 512)) * -(-Cout // 128) * B < 160
     else:
-        small = ((Lout + 511) // 512) * ((Cout + 63) // 64) * B < 256 and (Cout >= 256 or (Cout >= 64 and Lout * B <= 1024))
+        # few output channels: while positions are few too - or the reduction is long and the position-per-lane grid a handful of
+        # workgroups that each walk all of it (2048 -> 128, k = 3, 215 positions, B = 16: 1089 against 222 us)
+        small = Cout >= 64 and nwg64 < 256 and (Lout * B <= 1024 or (Cin >= 1024 and nwg64 <= 64))
+    small = small and B * Cin <= 65535          # (kalle_conv_pad_act puts B * C rows on one grid axis)
     if ((stride == 1 or dilation == 1) and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
             and (want == "1" or (want is None and small))):
         Lp = lib.kalle_conv_pad_len(Lout, K, stride, padding, dilation)
