@@ -360,7 +360,7 @@ int kalle_conv1d_fwd(const void* x, int x_dtype, const float* w_packed, const fl
  * x_padded [B][C][Lp] (`padding` leading zeros, Lp = kalle_conv_pad_len(...)), kalle_conv1d_cfirst_fwd convolves it (same
  * epilogue struct as kalle_conv1d_fwd; fp32 only).  Strided convs (dilation 1): pass phases = stride and padding =
  * ceil(padding / stride) * stride to kalle_conv_pad_act - the copy is then de-interleaved into `stride` phase rows so that a
- * tap's inputs for consecutive outputs are consecutive.  The caller owns x_padded. */
+ * tap's inputs for consecutive outputs are consecutive.  The caller owns x_padded.  Any B x C (rows ride on grid x). */
 int kalle_conv_pad_len(int Lout, int ksize, int stride, int padding, int dilation);
 int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding, const kalle_act* act,
                        int phases, void* stream);

@@ -76,7 +76,6 @@ def conv1d(x, w_packed, bias, *, Cout, K, stride=1, padding=0, dilation=1, act=0
         # few output channels: while positions are few too - or the reduction is long and the position-per-lane grid a handful of
         # workgroups that each walk all of it (2048 -> 128, k = 3, 215 positions, B = 16: 1089 against 222 us)
         small = Cout >= 64 and nwg64 < 256 and (Lout * B <= 1024 or (Cin >= 1024 and nwg64 <= 64))
-    small = small and B * Cin <= 65535          # (kalle_conv_pad_act puts B * C rows on one grid axis)
     if ((stride == 1 or dilation == 1) and act != 4 and x.dtype == torch.float32 and y.dtype == torch.float32
             and (want == "1" or (want is None and small))):
         Lp = lib.kalle_conv_pad_len(Lout, K, stride, padding, dilation)
@@ -151,11 +150,7 @@ def activate(x, act, alpha=None, beta=None, logscale=True):
     B, C, L = x.shape
     y = torch.empty_like(x)
     ia = _act_struct(act, alpha, beta, logscale, 0.0)
-    step = max(1, 65535 // C)                     # (kalle_conv_pad_act puts B * C rows on one grid axis)
-    for b0 in range(0, B, step):
-        nb = min(step, B - b0)
-        check(lib.kalle_conv_pad_act(_p(x[b0:b0 + nb]), _p(y[b0:b0 + nb]), nb, C, L, L, 0, ctypes.addressof(ia), 1, _stream()),
-              "kalle_conv_pad_act")
+    check(lib.kalle_conv_pad_act(_p(x), _p(y), B, C, L, L, 0, ctypes.addressof(ia), 1, _stream()), "kalle_conv_pad_act")
     return y
 
 

@@ -568,8 +568,9 @@ __global__ __launch_bounds__(256) void convT1d_v2_kernel(ConvParams p) {
 __global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ x, float* __restrict__ xp, int C, int Lin,
                                                       int Lp, int pad, int act, const float* __restrict__ aa,
                                                       const float* __restrict__ ab, int logscale, float act_param,
-                                                      int phases) {
-    const int row = blockIdx.y;                     // b * C + c
+                                                      int phases, int gx) {
+    const int row = blockIdx.x / gx;                // b * C + c (rows on grid x: B * C exceeds grid y's 65535 at 1024 channels x 64 chunks)
+    const int bx = blockIdx.x - row * gx;
     const int c = row % C;
     float a = act_param, inv_b = 0.f;
     if (act == 1) {
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void pad_act_kernel(const float* __restrict__ 
         if (logscale) { a = __expf(a); bb = __expf(bb); }
         inv_b = 1.f / (bb + 1e-9f);
     }
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < Lp; j += gridDim.x * 256) {
+    for (int j = bx * 256 + threadIdx.x; j < Lp; j += gx * 256) {
         const int li = j - pad;
         float v = 0.f;
         if (li >= 0 && li < Lin) {
@@ -1091,14 +1092,15 @@ extern "C" int kalle_conv_pad_len(int Lout, int ksize, int stride, int padding, 
 
 extern "C" int kalle_conv_pad_act(const float* x, float* x_padded, int B, int C, int Lin, int Lp, int padding,
                                   const kalle_act* act, int phases, void* stream) {
-    if (!x || !x_padded || B <= 0 || C <= 0 || Lin <= 0 || Lp <= 0 || padding < 0 || phases <= 0 || Lp % phases ||
-        (int64_t)B * C > 65535)
+    if (!x || !x_padded || B <= 0 || C <= 0 || Lin <= 0 || Lp <= 0 || padding < 0 || phases <= 0 || Lp % phases)
         return KALLE_ERR_ARG;
+    const int gx = (Lp + 255) / 256 > 64 ? 64 : (Lp + 255) / 256;
+    if ((int64_t)B * C * gx > 0x7fffffff) return KALLE_ERR_ARG;
     ActArgs a;
     if (!read_act(act, a, false)) return KALLE_ERR_ARG;
-    KALLE_LAUNCH(pad_act_kernel, dim3((Lp + 255) / 256 > 64 ? 64 : (Lp + 255) / 256, B * C), dim3(256), 0,
+    KALLE_LAUNCH(pad_act_kernel, dim3((unsigned)(B * C * gx)), dim3(256), 0,
                  static_cast<hipStream_t>(stream), x, x_padded, C, Lin, Lp, padding, a.code, a.alpha, a.beta, a.logscale, a.param,
-                 phases);
+                 phases, gx);
     return kalle_check_launch();
 }
 

@@ -753,3 +753,24 @@ def test_strided_conv_channels_per_lane_kernel(ops, dev, Cin, Cout, K, stride, p
     wp = conv_ops.weight_norm_fold(w, None)
     got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=2)
     assert got.shape == ref.shape and rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
+
+
+@pytest.mark.gpu
+def test_channels_per_lane_convs_with_many_batch_channel_rows(ops, dev):
+    """B x Cin > 65535 (all chunks of a long clip on the batch axis of a 1024-channel layer): the pad + activate pass carries its rows
+    on grid x; the strided 256+-channel convs pick the channels-per-lane kernel at every batch size (dispatch rule of round 3)"""
+    from kalle_audio_amd import conv_ops
+    B, Cin, Cout, K, stride, pad, L = 66, 1024, 256, 4, 2, 1, 24
+    assert B * Cin > 65535
+    x = _mk((B, Cin, L), dev, seed=140)
+    w = _mk((Cout, Cin, K), dev, seed=141) / (Cin * K) ** 0.5
+    bias = _mk((Cout,), dev, seed=142)
+    wp = conv_ops.weight_norm_fold(w, None)
+    got = conv_ops.conv1d(x, wp, bias, Cout=Cout, K=K, stride=stride, padding=pad, act=2)
+    ref = F.conv1d(F.elu(x), w, bias, stride=stride, padding=pad)
+    assert got.shape == ref.shape and rel_l2(got, ref) < 3e-5, rel_l2(got, ref)
+    w1 = _mk((Cout, Cin, 3), dev, seed=143) / (Cin * 3) ** 0.5
+    got = conv_ops.conv1d(x, conv_ops.weight_norm_fold(w1, None), bias, Cout=Cout, K=3, padding=1, act=2)
+    assert rel_l2(got, F.conv1d(F.elu(x), w1, bias, padding=1)) < 3e-5
+    y = conv_ops.activate(x, 2)
+    assert torch.equal(y, F.elu(x)) or rel_l2(y, F.elu(x)) < 1e-6
