@@ -98,7 +98,7 @@ def gemm(a, b, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=torch.bflo
         assert gate.dtype == torch.float32
     if residual is not None:
         assert residual.dtype == torch.float32
-    prof = KERNEL_TIMER
+    prof = KERNEL_TIMER if KERNEL_TIMER_ONLY is None else None     # (a filter names the grouped weight-gradient launch only)
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -144,6 +144,10 @@ def _workspace(device, nbytes):
 # bench.py sets this to a list to collect (kernel variant, algorithmic flops, start event, end event) per GEMM launch:
 # HIP events recorded on the launch stream, read back after the timed region (no host sync while timing).
 KERNEL_TIMER = None
+# Two event records per launch are not free (~8 us each on this stack: 300 GEMMs per step = 5 ms of a 220-ms step), so the timed
+# region of bench.py times ONLY the kernel named here (the dominant one: its roofline figure must come from the timed region) and
+# collects the table of all variants in one extra step afterwards.  None: every launch.
+KERNEL_TIMER_ONLY = None
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -619,7 +623,7 @@ def gemm_wgrad_group(problems, overwrite=False):
             return False
         assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
         assert dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1
-    prof = KERNEL_TIMER
+    prof = KERNEL_TIMER if KERNEL_TIMER_ONLY in (None, "gemm3_wgrad_group_kernel") else None
     for g in range(0, len(problems), MAX_GROUP):
         grp = problems[g:g + MAX_GROUP]
         arr = (_lib.WgradProblem * len(grp))()
