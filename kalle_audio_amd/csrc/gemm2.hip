@@ -1616,11 +1616,16 @@ int kalle_gemm_skinny_launch(const GemmParams& pin, bool a_km, bool b_km, bool f
             // x 6144 78 -> 65; but 2016 x 4608 x 1536 in 2.25 rounds 57 -> 65 and K = 12288 115 -> 122)
             if (pin.M > 512 && (tiles * sp > 256 || nk > 128)) continue;
             const double wgs = (double)tiles * sp;
-            const double rounds = wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0;           // one workgroup per CU at a time (80-128 KiB of LDS)
+            // 64 x 64 tiles (80 KiB of LDS) fit two to a CU and share its ingest - a fractional round is the right price; the larger
+            // tiles (120 / 128 KiB) run one per CU, so 288 of them ARE two rounds (M = 504, N = 4608: 128 x 64 tiles 28.3 us where
+            // 144 tiles of 128 x 128 take 19)
+            const double rounds = c == 0 ? (wgs / 256.0 > 1.0 ? wgs / 256.0 : 1.0) : (double)(((int64_t)wgs + 255) / 256);
             const double tk = (bm + bn) * 128.0 / 60e3;                            // us per K-tile: the CU's LDS-DMA ingest ...
             const double tk_floor = 0.30;                                          // ... or barrier + fragment reads + 16 MFMAs per wave
             double t = 2.5 + rounds * (3.0 + (double)((nk + sp - 1) / sp) * (tk > tk_floor ? tk : tk_floor));
-            if (sp > 1) t += 4.0 + 2.0 * sp * pin.M * (double)pin.N * 4.0 / 1.7e6;  // slabs: second launch + write + read back
+            // slabs: second launch + write + read back.  (The slabs of these shapes are a few MB that the finishing pass finds in L2 /
+            // Infinity Cache: 3 TB/s fits M = 252 ... 1008 x 1536 x 6144, where 1.7 TB/s kept M = 504 on whole-K 64 x 64 tiles at 37 us)
+            if (sp > 1) t += 4.0 + 2.0 * sp * pin.M * (double)pin.N * 4.0 / 3.0e6;
             const bool pick = forced ? (cand[c][0] == fwm && cand[c][1] == fwn && sp == fs) : t < best;
             if (pick) { best = t; wm = cand[c][0]; wn = cand[c][1]; splits = sp; }
         }
