@@ -16,11 +16,12 @@ for r in rows[:28]:
     name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:78]
     L.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
 rf = bd["roofline"]
-L += ["", "HIP-event timing inside bench.py (timed steps only, un-profiled run) per GEMM instantiation:\n",
+L += ["", "HIP-event timing inside bench.py per GEMM instantiation (un-profiled run; one extra step after the timed region with events "
+      "around every launch - inside the timed region only the roofline kernel is bracketed, two event records per launch cost ~8 us each):\n",
       "| variant | launches | avg us | TFLOP/s | share of step |", "|---|---|---|---|---|"]
 for k, v in sorted(rf["all_gemm_variants"].items(), key=lambda kv: -kv[1]["time_share_of_step"]):
     L.append(f"| `{k}` | {v['launches']} | {v['avg_us']:.1f} | {v['tflops']:.0f} | {100*v['time_share_of_step']:.1f} % |")
-L += ["", f"roofline kernel `{rf['kernel']}`: HIP events {rf['avg_launch_us']:.1f} us avg over {rf['launches']} launches (timed steps) = "
+L += ["", f"roofline kernel `{rf['kernel']}`: HIP events {rf['avg_launch_us']:.1f} us avg over {rf['launches']} launches ({rf.get('hip_events_in', 'the timed region')}) = "
       f"{rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f} % of the 2.5 PFLOP/s dense-bf16 peak; the rocprof row of the same instantiation "
       "averages all profiled steps.", "",
       f"HBM-side traffic (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, {tag[:3]}_pmc_hbm_traffic_b256.json; FETCH doubled per the gfx950 "
