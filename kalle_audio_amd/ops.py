@@ -144,7 +144,7 @@ def _workspace(device, nbytes):
 # bench.py sets this to a list to collect (kernel variant, algorithmic flops, start event, end event) per GEMM launch:
 # HIP events recorded on the launch stream, read back after the timed region (no host sync while timing).
 KERNEL_TIMER = None
-# Two event records per launch are not free (~8 us each on this stack: 300 GEMMs per step = 5 ms of a 220-ms step), so the timed
+# Two event records per launch are not free (~4.5 us each on this stack: 300 GEMMs per step = 2.7 ms of a 222-ms step), so the timed
 # region of bench.py times ONLY the kernel named here (the dominant one: its roofline figure must come from the timed region) and
 # collects the table of all variants in one extra step afterwards.  None: every launch.
 KERNEL_TIMER_ONLY = None

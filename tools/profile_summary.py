@@ -17,7 +17,7 @@ for r in rows[:28]:
     L.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
 rf = bd["roofline"]
 L += ["", "HIP-event timing inside bench.py per GEMM instantiation (un-profiled run; one extra step after the timed region with events "
-      "around every launch - inside the timed region only the roofline kernel is bracketed, two event records per launch cost ~8 us each):\n",
+      "around every launch - inside the timed region only the roofline kernel is bracketed, two event records per launch cost ~4.5 us each):\n",
       "| variant | launches | avg us | TFLOP/s | share of step |", "|---|---|---|---|---|"]
 for k, v in sorted(rf["all_gemm_variants"].items(), key=lambda kv: -kv[1]["time_share_of_step"]):
     L.append(f"| `{k}` | {v['launches']} | {v['avg_us']:.1f} | {v['tflops']:.0f} | {100*v['time_share_of_step']:.1f} % |")
