@@ -195,6 +195,14 @@ def test_colsum(ops, dev):
     assert rel_l2(ops.colsum(x), x.sum(0)) < 1e-5
     xb = x.bfloat16()
     assert rel_l2(ops.colsum(xb), xb.float().sum(0)) < 1e-5
+    # many rows, column slices of a wider matrix (row stride > columns, bases on and off the 16-byte grid), accumulating
+    big = _mk((3000, 2048), dev, seed=20)
+    for t in (big, big.bfloat16()):
+        for view in (t[:2016, :1536], t[:, 8:1544], t[:, 4:1540], t[:1000, 512:]):
+            want = view.float().sum(0)
+            assert rel_l2(ops.colsum(view), want) < 1e-5, (t.dtype, tuple(view.shape), view.storage_offset())
+            acc = torch.ones(view.shape[1], device=dev)
+            assert rel_l2(ops.colsum(view, out=acc, accumulate=True), want + 1.0) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ elementwise
