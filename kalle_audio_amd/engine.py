@@ -15,6 +15,7 @@ bucketed NCCL all-reduce] -> optimizer.step -> scheduler.step -> barrier) around
     the 1/world_size gradient averaging in (no separate scale pass, no per-step host sync, no barrier).
 """
 import math
+import contextlib
 import os
 
 import torch
@@ -211,13 +212,25 @@ class DataParallelTrainer:
         self.exp_avg = torch.zeros_like(self.flat.param)
         self.exp_avg_sq = torch.zeros_like(self.flat.param)
         self._pending = []
+        # Sharded optimizer (KALLE_SHARD_OPTIMIZER=1, off by default; world a power of two <= 64, fp32 buckets): a block bucket's
+        # all-reduce is issued as its two halves with the optimizer in the middle - reduce-scatter of the matrix gradients, the fused Adam
+        # on this rank's 1 / world of them, all-gather of the updated fp32 weights (the same bytes on the links as the all-reduce; the
+        # Adam pass shrinks from 31.5 GB to 31.5 / world GB per rank and step, the bf16 mirror is re-cast from the gathered weights).
+        # The vectors at the head of a bucket (norm scales, biases) stay all-reduced and are updated on every rank; so do the buckets
+        # outside the blocks.  Moments exist on their owner only: state_dict() gathers them (a collective - call it on every rank).
+        self.shard_opt = (os.environ.get("KALLE_SHARD_OPTIMIZER", "0") == "1" and comm_dtype == torch.float32
+                          and self.world & (self.world - 1) == 0 and self.world <= 64)
+        self._shard_bufs = {}
         # Optimizer overlapped with the backward pass: a block's bucket is final as soon as its backward kernels are queued (and
         # its all-reduce has landed), so its slice of the fused Adam runs right then on a side stream - an HBM-bound pass under
         # the MFMA-bound GEMMs of the blocks still to come - instead of one 5.4 ms pass over all 1.05 B parameters at the end.
         # (KALLE_OVERLAP_ADAM=0: the single pass at the end of the step.)
         self.overlap_adam = device.type == "cuda" and os.environ.get("KALLE_OVERLAP_ADAM", "1") != "0"
-        self._opt_stream = torch.cuda.Stream(device=device) if self.overlap_adam else None
-        self._comm_stream = torch.cuda.Stream(device=device) if self.overlap_adam else None
+        side = self.overlap_adam or (device.type == "cuda" and self.shard_opt)
+        self._opt_stream = torch.cuda.Stream(device=device) if side else None
+        self._comm_stream = torch.cuda.Stream(device=device) if side else None
+        self._comm_events = 0
+        self._shard_ev = None
         self._opt_done = set()            # bucket keys whose Adam slice of the current optimizer step has been queued
         self._opt_lr = None               # learning rate of the optimizer step in progress (set when its backward starts)
         self._overlap_now = False         # decided per optimizer step: only where the backward GEMMs are long enough to hide it
@@ -286,11 +299,85 @@ class DataParallelTrainer:
             for key in keys:
                 self._adam_bucket(key)
 
+    # -- sharded optimizer -------------------------------------------------------------------------------------
+    def _shard_range(self, key):
+        """(vector start, matrix start, bucket end, elements per rank, this rank's first element) of a block bucket"""
+        s0, s1 = self.flat.small_range[key]
+        b1 = self.flat.bucket_range[key][1]
+        c = (b1 - s1) // self.world              # (parameters are laid out on 64-element boundaries: any power of two <= 64 divides)
+        return s0, s1, b1, c, s1 + self.rank * c
+
+    def _sharded_active(self):
+        return self.shard_opt and self._comm_active()
+
+    def _sharded_bucket(self, key, ev):
+        """reduce-scatter -> Adam on the own chunk (and on the all-reduced vectors) -> all-gather of the fp32 weights -> bf16 mirror.
+        On the GPU: collectives on the comm stream, Adam on the optimizer stream, both behind the backward pass's event; on the CPU
+        (gloo tests) the same calls in order."""
+        f = self.flat
+        s0, s1, b1, c, o0 = self._shard_range(key)
+        cuda = f.grad.is_cuda
+        comm = torch.cuda.stream(self._comm_stream) if cuda else contextlib.nullcontext()
+        opt = torch.cuda.stream(self._opt_stream) if cuda else contextlib.nullcontext()
+        shard = self._shard_bufs.get(c)
+        if shard is None:
+            shard = self._shard_bufs[c] = torch.empty(c, device=f.grad.device, dtype=torch.float32)
+        with comm:
+            if cuda:
+                self._comm_stream.wait_event(ev)
+                if self._shard_ev is not None:
+                    self._comm_stream.wait_event(self._shard_ev)      # the previous bucket's Adam has read the shared chunk buffer
+            w_vec = dist.all_reduce(f.grad[s0:s1], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) if s1 > s0 else None
+            w_rs = dist.reduce_scatter_tensor(shard, f.grad[s1:b1], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) if c else None
+        with opt:
+            if cuda:
+                self._opt_stream.wait_event(ev)
+            for w in (w_vec, w_rs):
+                if w is not None:
+                    w.wait()
+            self._adam_range(s0, s1)
+            self._adam_range(o0, o0 + c, grad=shard)
+            ev2 = None
+            if cuda:
+                ev2 = torch.cuda.Event()
+                ev2.record(self._opt_stream)
+                self._shard_ev = ev2
+        with comm:
+            if cuda:
+                self._comm_stream.wait_event(ev2)
+            if c:
+                own = f.param[o0:o0 + c] if cuda else f.param[o0:o0 + c].clone()    # (RCCL gathers in place; gloo gets a copy)
+                dist.all_gather_into_tensor(f.param[s1:b1], own, group=self.pg, async_op=True).wait()
+                if f.param_bf16 is not None:
+                    if cuda:
+                        ops.copy_rows(f.param[s1:b1], f.param_bf16[s1:b1], 1, 1, b1 - s1, 0, b1 - s1, 0, b1 - s1)
+                    else:
+                        f.param_bf16[s1:b1].copy_(f.param[s1:b1])
+        self._comm_events += 1
+        self._opt_done.add(key)
+
+    def gather_moments(self):
+        """sharded optimizer: every rank receives the Adam moments of the chunks it does not own (a collective; state_dict() calls it)"""
+        if not self._sharded_active():
+            return
+        for _, blk in self.blocks:
+            s0, s1, b1, c, o0 = self._shard_range(blk._kalle_bucket_key)
+            if c:
+                for buf in (self.exp_avg, self.exp_avg_sq):
+                    dist.all_gather_into_tensor(buf[s1:b1], buf[o0:o0 + c].clone(), group=self.pg)
+
     def _on_block_done(self, blk):
         """called (from autograd's backward) right after a block's backward kernels were queued"""
         if not self._boundary():
             return
         key = blk._kalle_bucket_key
+        if self._sharded_active():
+            ev = None
+            if self.flat.grad.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+            self._sharded_bucket(key, ev)
+            return
         if not self._overlap_now:
             self._allreduce(self.flat.bucket_grad(key))
             return
@@ -307,17 +394,18 @@ class DataParallelTrainer:
         self._opt_lr = self.lr * (self.lr_schedule(k - 1) if self.lr_schedule else 1.0)
         self._opt_done = set()
         self._comm_events = 0
+        self._shard_ev = None
 
     def _adam_bucket(self, key):
         a, b = self.flat.bucket_range[key]
         self._adam_range(a, b)
         self._opt_done.add(key)
 
-    def _adam_range(self, a, b):
+    def _adam_range(self, a, b, grad=None):
         if b <= a:
             return
         f = self.flat
-        ops.adam_step(f.param[a:b], f.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
+        ops.adam_step(f.param[a:b], f.grad[a:b] if grad is None else grad, self.exp_avg[a:b], self.exp_avg_sq[a:b],
                       f.param_bf16[a:b] if f.param_bf16 is not None else None, lr=self._opt_lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, decoupled=self.decoupled,
                       step=self.step_count + 1, grad_scale=1.0 / (self.world * self.grad_accum_steps))
@@ -339,6 +427,8 @@ class DataParallelTrainer:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             cur.wait_stream(self._opt_stream)
+            if self._sharded_active():
+                cur.wait_stream(self._comm_stream)          # the all-gathers of the updated weights and their bf16 re-cast
             if timed:
                 e1.record()
                 self.comm_timing.append((e0, e1, self._comm_events))
@@ -347,6 +437,11 @@ class DataParallelTrainer:
             for key in ("_rest", "_vae"):
                 if key in self.flat.bucket_range:
                     self._allreduce(self.flat.bucket_grad(key))
+            if self._sharded_active() and self.flat.grad.is_cuda and self._opt_stream is not None:
+                # (small micro-batches keep the single optimizer pass for what is left; the sharded buckets ran on the side streams)
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._opt_stream)
+                cur.wait_stream(self._comm_stream)
         timed = self.comm_timing is not None and self._pending and self.flat.grad.is_cuda
         if timed:
             # exposed (not overlapped) all-reduce time = how long the compute stream sits in the waits below: nothing is
@@ -368,7 +463,8 @@ class DataParallelTrainer:
         ev = self.comm_timing or []
         active = dist.is_initialized() and (self.world > 1 or bool(os.environ.get("KALLE_FORCE_COMM")))
         out = {"ranks": self.world, "backend": dist.get_backend(self.pg) if dist.is_initialized() else None,
-               "allreduce_active": bool(active), "comm_dtype": str(self.comm_dtype).replace("torch.", ""),
+               "allreduce_active": bool(active), "sharded_optimizer": bool(active and self.shard_opt),
+               "comm_dtype": str(self.comm_dtype).replace("torch.", ""),
                "buckets_per_step": ev[0][2] if ev else 0,
                "exposed_ms_per_step": (sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev)) if ev else 0.0}
         return out
@@ -463,6 +559,7 @@ class DataParallelTrainer:
     # -- checkpointing (reference: weights only, train_offline.py:261-263; here the optimizer, schedule position, gradient-
     #    accumulation phase and the EMA too, so that a resumed run continues bit for bit) -------------------------------------
     def state_dict(self):
+        self.gather_moments()
         sd = {"model": self.model.state_dict(), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
               "step": self.step_count, "micro": self.micro,
               # the moments are raw flat tensors: their meaning is the flat layout (name -> (offset, numel)), which travels with

@@ -138,3 +138,82 @@ def test_trainer_lr_matches_transformers_cosine_schedule(monkeypatch):
             tr.optimizer_step()
             assert abs(tr.last_lr - want) <= 1e-12 + 1e-9 * want, (offset, k, tr.last_lr, want)
             ref_opt.step(); ref.step()
+
+
+def _fake_adam(param, grad, exp_avg, exp_avg_sq, param_bf16, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+               decoupled=False, step=1, grad_scale=1.0):
+    """stand-in for the fused HIP Adam on the CPU (the plumbing is what these tests are about): same state, same call"""
+    g = grad * grad_scale
+    exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    param.sub_(lr * exp_avg / (exp_avg_sq.sqrt() + eps))
+    if param_bf16 is not None:
+        param_bf16.copy_(param)
+
+
+def _shard_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        import copy
+        from kalle_audio_amd import engine, ops
+        from kalle_audio_amd.stable_audio_tools.models.dit import DiffusionTransformer
+        engine.init_distributed(backend="gloo")
+        ops.adam_step = _fake_adam
+        torch.manual_seed(7)
+        model = DiffusionTransformer(io_channels=16, embed_dim=128, depth=2, num_heads=2, cond_token_dim=64,
+                                     global_cond_dim=32, transformer_type="continuous_transformer")
+        ref_model = copy.deepcopy(model)
+        os.environ["KALLE_SHARD_OPTIMIZER"] = "1"
+        tr = engine.DataParallelTrainer(model, lr=1e-2)
+        os.environ["KALLE_SHARD_OPTIMIZER"] = "0"
+        ref = engine.DataParallelTrainer(ref_model, lr=1e-2)
+        assert tr.shard_opt and tr._sharded_active() and not ref._sharded_active()
+        for ostep in range(3):
+            for t in (tr, ref):
+                # per-rank gradients: a rank- and position-dependent pattern of small integers (sums are exact in fp32)
+                gen = torch.Generator().manual_seed(1000 * ostep + rank)
+                t.flat.grad.copy_(torch.randint(-3, 4, (t.flat.total,), generator=gen).float())
+                t._begin_optimizer_step()
+                for _, blk in reversed(t.blocks):
+                    t._on_block_done(blk)
+                t._finish_comm()
+                t.optimizer_step()
+                t.micro += 1
+            assert torch.equal(tr.flat.param, ref.flat.param), (ostep, (tr.flat.param - ref.flat.param).abs().max())
+            assert torch.equal(tr.flat.param_bf16, ref.flat.param_bf16)
+            chk = tr.flat.param.clone()
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            assert torch.equal(chk, tr.flat.param)             # every rank holds the same weights
+        # the moments live on their owner until gathered: state_dict() makes them whole on every rank
+        s0, s1, b1, c, o0 = tr._shard_range(tr.blocks[0][1]._kalle_bucket_key)
+        assert c > 0 and (b1 - s1) == c * world
+        if world > 1:
+            other = s1 + ((rank + 1) % world) * c
+            assert torch.count_nonzero(tr.exp_avg[other:other + c]) == 0
+        sd = tr.state_dict()
+        assert torch.equal(sd["exp_avg"], ref.exp_avg) and torch.equal(sd["exp_avg_sq"], ref.exp_avg_sq)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_optimizer_equals_allreduce_path_gloo(world):
+    """KALLE_SHARD_OPTIMIZER=1: reduce-scatter -> Adam on 1 / world of a block's matrices -> all-gather of the weights gives bit-identical
+    weights (and, once gathered, moments) to all-reduce + Adam on everything, on every rank (CPU, gloo, a torch stand-in for the kernel)"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

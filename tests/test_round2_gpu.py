@@ -730,6 +730,20 @@ for name, cd in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
     torch.cuda.synchronize()
     s = tr.comm_summary()
     res[name] = {"grad": R.rel(tr.flat.grad, base_g), "param": R.rel(tr.flat.param, base_p), "summary": s}
+# sharded optimizer (KALLE_SHARD_OPTIMIZER=1): reduce-scatter -> Adam on the own chunk -> all-gather -> bf16 mirror, on RCCL (one rank),
+# with the per-bucket overlap and with the single optimizer pass of small micro-batches
+os.environ["KALLE_SHARD_OPTIMIZER"] = "1"
+for name, min_rows in (("shard", 0), ("shard_small", 1 << 30)):
+    m = R._small_dit(dev); tr = engine.DataParallelTrainer(m, lr=1e-3, optimizer="Adam")
+    assert tr._sharded_active()
+    tr.overlap_min_rows = min_rows
+    for _ in range(2): tr.train_step(m, lat, t, noise, cond)
+    torch.cuda.synchronize()
+    sd = tr.state_dict()
+    res[name] = {"grad": R.rel(tr.flat.grad, base_g), "param": R.rel(tr.flat.param, base_p),
+                 "mirror": float((tr.flat.param_bf16.float() - tr.flat.param.bfloat16().float()).abs().max()),
+                 "moments": bool(torch.count_nonzero(sd["exp_avg_sq"]) > 0.5 * sd["exp_avg_sq"].numel())}
+os.environ["KALLE_SHARD_OPTIMIZER"] = "0"
 # gradient accumulation: the all-reduce fires on the boundary micro-batch only
 m = R._small_dit(dev); tr = engine.DataParallelTrainer(m, lr=1e-3, optimizer="Adam", grad_accum_steps=2)
 tr.comm_timing = []
@@ -766,6 +780,8 @@ def test_rccl_path_world1_forced_comm(dev, tmp_path):
         assert sm["backend"] == "nccl" and sm["ranks"] == 1 and sm["allreduce_active"] and sm["buckets_per_step"] == 3, sm
         assert sm["exposed_ms_per_step"] >= 0.0
     assert res["accum_events"] == 2
+    for k in ("shard", "shard_small"):       # same kernels on the same gradients: the weights of the plain run, mirror = bf16(weights)
+        assert res[k]["grad"] < 1e-4 and res[k]["param"] < 1e-6 and res[k]["mirror"] == 0.0 and res[k]["moments"], (k, res[k])
 
 
 # ------------------------------------------------------------------------------------------------ grouped weight gradients
